@@ -1,0 +1,10 @@
+"""benlsip.jl_amd — MI355X (gfx950) backend for BEnlsip.jl's trust-region subproblem hot path.
+
+Only what the path needs lives here: ``csrc/`` (HIP kernels + the C ABI of ``include/benlsip_hip.h``),
+the ctypes binding and the host-side mirror of the reference's operator interface.
+"""
+from . import _lib, build  # noqa: F401
+from ._lib import BenlsipHipError, init, library_path, load  # noqa: F401
+from .distributed import init_distributed, row_shard  # noqa: F401
+from .operators import (AlHessian, CGStatus, DeviceVector, MixedConstraints, factor_to_boundary, hmul, left_mul,  # noqa: F401
+                        left_mul_tr, pack_bitvector, projected_cg, projected_cg_dev, projection, projection_, vthv)

@@ -1,0 +1,1015 @@
+// bh_api.hip — C ABI (include/benlsip_hip.h) over the gfx950 kernels of bh_kernels.hip.h.
+// One process drives one GPU; all launches go to one stream; every export is synchronous.
+#include "../../include/benlsip_hip.h"
+#include "bh_kernels.hip.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: librccl is dlopen'ed in bh_comm_init (never needed on one GPU)
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace bh;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct CgWorkspace {
+    int64_t n_pad = 0;
+    double *w = nullptr, *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr, *g = nullptr, *wl = nullptr, *wu = nullptr;
+    double* slab = nullptr;
+    CgState* d_state = nullptr;
+    CgState* h_state = nullptr;   // pinned, 2 slots
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    double* d_trace = nullptr;
+    int64_t trace_cap = 0;
+};
+
+struct Ctx {
+    bool init = false;
+    int device = -1;
+    int flags = 0;
+    int n_cu = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string detail;
+    // options
+    int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
+    int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
+    int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    // RCCL
+    void* rccl_lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    ncclResult_t (*p_ncclGetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*p_ncclCommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*p_ncclCommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*p_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*p_ncclGetErrorString)(ncclResult_t) = nullptr;
+    CgWorkspace cg;
+    double* scratch_dev = nullptr;   // small device scratch (selftest, f2b)
+};
+
+Ctx g_ctx;
+
+int32_t fail(int32_t code, const std::string& what) {
+    g_ctx.detail = what;
+    return code;
+}
+
+#define BH_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(BH_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));               \
+    } while (0)
+
+#define BH_NCCL(call)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t r__ = (call);                                                                     \
+        if (r__ != ncclSuccess)                                                                        \
+            return fail(BH_ERR_RCCL, std::string(#call) + ": " +                                      \
+                                         (g_ctx.p_ncclGetErrorString ? g_ctx.p_ncclGetErrorString(r__) : "?")); \
+    } while (0)
+
+#define BH_REQUIRE_INIT() \
+    do { if (!g_ctx.init) return fail(BH_ERR_NOT_INIT, "bh_init has not been called"); } while (0)
+
+#define BH_TRY(expr) do { int32_t rc__ = (expr); if (rc__ != BH_OK) return rc__; } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+template <class T>
+int32_t dev_alloc(T** out, int64_t count) {
+    *out = nullptr;
+    if (count <= 0) count = 1;
+    BH_HIP(hipMalloc(reinterpret_cast<void**>(out), (size_t)count * sizeof(T)));
+    return BH_OK;
+}
+
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+
+// ------------------------------------------------------------------------------------------
+// row-stream kernel geometry
+// ------------------------------------------------------------------------------------------
+struct RsConfig { int T, CPT, R, blocks_per_cu; };
+
+// index -> template instantiation (see launch_row_stream)
+const RsConfig kRsConfigs[] = {
+    {64, 1, 8, 8},     // 0: nchunks <= 64    (n <= 128)
+    {256, 1, 8, 4},    // 1: nchunks <= 256   (n <= 512)
+    {256, 2, 8, 4},    // 2: nchunks <= 512   (n <= 1024)
+    {256, 4, 4, 4},    // 3: nchunks <= 1024  (n <= 2048)
+    {256, 8, 4, 2},    // 4: nchunks <= 2048  (n <= 4096)   variant 0
+    {512, 8, 2, 1},    // 5: nchunks <= 4096  (n <= 8192)
+    {512, 4, 4, 2},    // 6: nchunks <= 2048  variant 1
+    {256, 8, 2, 3},    // 7: nchunks <= 2048  variant 2
+    {1024, 2, 4, 1},   // 8: nchunks <= 2048  variant 3
+    {512, 4, 2, 3},    // 9: nchunks <= 2048  variant 4
+};
+constexpr int64_t kMaxChunks = 4096;
+
+int pick_config(int nchunks) {
+    if (nchunks <= 64) return 0;
+    if (nchunks <= 256) return 1;
+    if (nchunks <= 512) return 2;
+    if (nchunks <= 1024) return 3;
+    if (nchunks <= 2048) {
+        switch (g_ctx.opt_variant) {
+            case 1: return 6;
+            case 2: return 7;
+            case 3: return 8;
+            case 4: return 9;
+            default: return 4;
+        }
+    }
+    return 5;
+}
+
+template <int T, int CPT, int R>
+void launch_rs_mode(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
+    switch (mode) {
+        case MODE_JV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JV>), dim3(grid), dim3(T), 0, s, a); break;
+        case MODE_JTV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JTV>), dim3(grid), dim3(T), 0, s, a); break;
+        default: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED>), dim3(grid), dim3(T), 0, s, a); break;
+    }
+}
+
+void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
+    switch (cfg) {
+        case 0: launch_rs_mode<64, 1, 8>(mode, a, grid, s); break;
+        case 1: launch_rs_mode<256, 1, 8>(mode, a, grid, s); break;
+        case 2: launch_rs_mode<256, 2, 8>(mode, a, grid, s); break;
+        case 3: launch_rs_mode<256, 4, 4>(mode, a, grid, s); break;
+        case 4: launch_rs_mode<256, 8, 4>(mode, a, grid, s); break;
+        case 5: launch_rs_mode<512, 8, 2>(mode, a, grid, s); break;
+        case 6: launch_rs_mode<512, 4, 4>(mode, a, grid, s); break;
+        case 7: launch_rs_mode<256, 8, 2>(mode, a, grid, s); break;
+        case 8: launch_rs_mode<1024, 2, 4>(mode, a, grid, s); break;
+        default: launch_rs_mode<512, 4, 2>(mode, a, grid, s); break;
+    }
+}
+
+int grid_for(int cfg, int64_t nrows) {
+    const RsConfig& c = kRsConfigs[cfg];
+    const int64_t ngroups = (nrows + c.R - 1) / c.R;
+    const int64_t bpc = g_ctx.opt_blocks_per_cu > 0 ? g_ctx.opt_blocks_per_cu : c.blocks_per_cu;
+    int64_t g = (int64_t)g_ctx.n_cu * bpc;
+    g = std::min<int64_t>(g, std::max<int64_t>(ngroups, 1));
+    return (int)g;
+}
+
+constexpr int kEvCap = 512;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------
+struct bh_hess {
+    int64_t d = 0, n = 0, q = 0, q_eff = 0, ld = 0;
+    int nchunks = 0;
+    double mu = 0.0;
+    double* Jd = nullptr;          // (d + q) x ld row-major
+    double* vpad = nullptr;        // ld
+    double* zpad = nullptr;        // ld
+    double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
+    double* partials = nullptr;    // g_cap x ld
+    double* sq_partials = nullptr; // g_cap
+    double* scalar = nullptr;      // 2
+    int g_cap = 0;
+    bh_stats_t stats{};
+    std::vector<hipEvent_t> ev;    // 2*kEvCap, created lazily
+};
+
+struct bh_proj {
+    int64_t mA = 0, n = 0, ldA = 0;
+    double* Ad = nullptr;          // mA x ldA row-major
+    int nfix = 0, mpp = 0;
+    bool active_set = false;
+    int* fixrank = nullptr;        // ldA ints
+    int* fixidx = nullptr;         // n ints
+    double* L = nullptr;           // mpp x mpp
+    int64_t L_cap = 0;
+    double* tw = nullptr;          // n + 16
+    double* rpad = nullptr;        // ldA
+    double* vtmp = nullptr;        // ldA
+};
+
+namespace {
+
+int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
+    CgWorkspace& c = g_ctx.cg;
+    if (c.n_pad < n_pad) {
+        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.g, &c.wl, &c.wu};
+        dev_free(c.slab);
+        c.slab = nullptr;
+        BH_TRY(dev_alloc(&c.slab, 8 * n_pad));
+        BH_HIP(hipMemsetAsync(c.slab, 0, (size_t)8 * n_pad * sizeof(double), g_ctx.stream));
+        for (int i = 0; i < 8; ++i) *vecs[i] = c.slab + (int64_t)i * n_pad;
+        c.n_pad = n_pad;
+    }
+    if (!c.d_state) {
+        BH_TRY(dev_alloc(&c.d_state, 1));
+        BH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.h_state), 2 * sizeof(CgState), hipHostMallocDefault));
+        BH_HIP(hipEventCreateWithFlags(&c.ev[0], hipEventDisableTiming));
+        BH_HIP(hipEventCreateWithFlags(&c.ev[1], hipEventDisableTiming));
+    }
+    if (trace_cap > c.trace_cap) {
+        dev_free(c.d_trace);
+        c.d_trace = nullptr;
+        BH_TRY(dev_alloc(&c.d_trace, 4 * trace_cap));
+        c.trace_cap = trace_cap;
+    }
+    return BH_OK;
+}
+
+int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H) {
+    if (g_ctx.nranks <= 1 || g_ctx.comm == nullptr) return BH_OK;
+    BH_NCCL(g_ctx.p_ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_ctx.comm, g_ctx.stream));
+    if (H) H->stats.n_allreduce += 1;
+    return BH_OK;
+}
+
+// z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
+int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index) {
+    const int cfg = pick_config(H->nchunks);
+    const int64_t nrows = H->d + H->q_eff;
+    const int grid = grid_for(cfg, nrows);
+    RowStreamArgs a{};
+    a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
+    a.v = v_pad; a.u = nullptr; a.t_out = nullptr; a.partials = H->partials; a.sq_partials = nullptr;
+    a.mu = H->mu; a.state = state;
+    const bool timed = (g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0 && ev_index < kEvCap;
+    if (timed) {
+        if (H->ev.empty()) {
+            H->ev.resize(2 * kEvCap, nullptr);
+            for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
+        }
+        BH_HIP(hipEventRecord(H->ev[2 * ev_index], g_ctx.stream));
+    }
+    launch_row_stream(cfg, MODE_FUSED, a, grid, g_ctx.stream);
+    if (timed) BH_HIP(hipEventRecord(H->ev[2 * ev_index + 1], g_ctx.stream));
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
+                       H->partials, H->ld, H->nchunks, grid, z_out, state);
+    BH_HIP(hipGetLastError());
+    BH_TRY(allreduce_inplace(z_out, H->n, H));
+    return BH_OK;
+}
+
+int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_rows, double* sq_out_scalar) {
+    const int cfg = pick_config(H->nchunks);
+    const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
+    const int grid = grid_for(cfg, nrows);
+    RowStreamArgs a{};
+    a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
+    a.v = v_pad; a.t_out = t_out; a.partials = nullptr;
+    a.sq_partials = sq_out_scalar ? H->sq_partials : nullptr;
+    a.mu = H->mu; a.state = nullptr;
+    launch_row_stream(cfg, MODE_JV, a, grid, g_ctx.stream);
+    if (sq_out_scalar) {
+        hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, g_ctx.stream, H->sq_partials, grid, sq_out_scalar);
+    }
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out) {
+    const int cfg = pick_config(H->nchunks);
+    const int64_t nrows = H->d;
+    const int grid = grid_for(cfg, nrows);
+    RowStreamArgs a{};
+    a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
+    a.v = nullptr; a.u = u_dev; a.t_out = nullptr; a.partials = H->partials; a.sq_partials = nullptr;
+    a.mu = H->mu; a.state = nullptr;
+    launch_row_stream(cfg, MODE_JTV, a, grid, g_ctx.stream);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
+                       H->partials, H->ld, H->nchunks, grid, z_out, (const CgState*)nullptr);
+    BH_HIP(hipGetLastError());
+    BH_TRY(allreduce_inplace(z_out, H->n, H));
+    return BH_OK;
+}
+
+int32_t alloc_hess_common(bh_hess* H) {
+    const int64_t rows = H->d + H->q;
+    H->ld = round_up(std::max<int64_t>(H->n, 1), 16);
+    H->nchunks = (int)(H->ld / 2);
+    if (H->nchunks > kMaxChunks)
+        return fail(BH_ERR_UNSUPPORTED, "n > 8192 is not supported by the register-resident row kernels yet");
+    H->q_eff = (g_ctx.rank == 0) ? H->q : 0;   // C is replicated: only rank 0 contributes C'(mu C v)
+    BH_TRY(dev_alloc(&H->Jd, std::max<int64_t>(rows, 1) * H->ld));
+    BH_TRY(dev_alloc(&H->vpad, H->ld));
+    BH_TRY(dev_alloc(&H->zpad, H->ld));
+    BH_TRY(dev_alloc(&H->upad, std::max<int64_t>(rows, 1)));
+    BH_HIP(hipMemsetAsync(H->vpad, 0, H->ld * sizeof(double), g_ctx.stream));
+    BH_HIP(hipMemsetAsync(H->zpad, 0, H->ld * sizeof(double), g_ctx.stream));
+    // partial slabs: enough for the largest grid any variant may use
+    int64_t gmax = (int64_t)g_ctx.n_cu * 8;
+    H->g_cap = (int)gmax;
+    BH_TRY(dev_alloc(&H->partials, gmax * H->ld));
+    BH_TRY(dev_alloc(&H->sq_partials, gmax));
+    BH_TRY(dev_alloc(&H->scalar, 2));
+    H->stats.bytes_per_hmul = 8.0 * (double)(H->d + H->q_eff) * (double)H->n + 16.0 * (double)H->n;
+    return BH_OK;
+}
+
+// Upload a column-major host matrix (rows x cols, leading dimension ldh) into rows [row0, row0+rows) of a
+// row-major padded device image with leading dimension ldd.
+int32_t upload_transposed(const double* host, int64_t rows, int64_t cols, int64_t ldh, double* dst_image, int64_t row0,
+                          int64_t ldd) {
+    if (rows == 0) return BH_OK;
+    double* staging = nullptr;
+    BH_TRY(dev_alloc(&staging, rows * std::max<int64_t>(cols, 1)));
+    if (cols > 0) {
+        hipError_t e = hipMemcpy2DAsync(staging, (size_t)rows * sizeof(double), host, (size_t)ldh * sizeof(double),
+                                        (size_t)rows * sizeof(double), (size_t)cols, hipMemcpyHostToDevice, g_ctx.stream);
+        if (e != hipSuccess) { dev_free(staging); return fail(BH_ERR_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e)); }
+    }
+    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((ldd + 31) / 32));
+    hipLaunchKernelGGL(transpose_cm_to_rm_kernel, grid, dim3(256), 0, g_ctx.stream, staging, rows, rows, cols,
+                       dst_image + row0 * ldd, ldd);
+    hipError_t e = hipStreamSynchronize(g_ctx.stream);
+    dev_free(staging);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("transpose: ") + hipGetErrorString(e));
+    return BH_OK;
+}
+
+int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_device) {
+    if (n == 0) return BH_OK;
+    BH_HIP(hipMemcpyAsync(dst_pad, src, (size_t)n * sizeof(double), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                          g_ctx.stream));
+    return BH_OK;
+}
+
+int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_device) {
+    if (n == 0) return BH_OK;
+    BH_HIP(hipMemcpyAsync(dst, src_dev, (size_t)n * sizeof(double), dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                          g_ctx.stream));
+    return BH_OK;
+}
+
+// ---- projection -------------------------------------------------------------------------
+ProjArgs proj_args(bh_proj* P, const CgState* st) {
+    ProjArgs a{};
+    a.A = P->Ad; a.ldA = P->ldA; a.mA = (int)P->mA; a.n = (int)P->n; a.nfix = P->nfix; a.mpp = P->mpp;
+    a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
+    a.fixidx = P->fixidx; a.L = P->L; a.tw = P->tw; a.state = st;
+    return a;
+}
+
+// v_out = P(r_pad): r_pad is a zero-padded ldA-length device vector, v_out has >= n entries.
+int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgState* st) {
+    const int n = (int)P->n;
+    if (P->mA == 0) {
+        const int grid = std::max(1, std::min((n + 255) / 256, 1024));
+        hipLaunchKernelGGL(proj_mask_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, r_pad, v_out,
+                           P->nfix > 0 ? P->fixrank : (const int*)nullptr, n, st);
+        BH_HIP(hipGetLastError());
+        return BH_OK;
+    }
+    ProjArgs a = proj_args(P, st);
+    const int grid1 = (a.mA + 3) / 4 + (a.nfix + 255) / 256;
+    hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, r_pad);
+    const size_t lds = ((size_t)((a.mpp + 1) & ~1) + 64 * 65) * sizeof(double);
+    hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), lds, g_ctx.stream, a);
+    const int nch = (n + 1) / 2;
+    hipLaunchKernelGGL((proj_left_mul_tr_kernel<true>), dim3((nch + 255) / 256), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+int32_t check_proj_ready(bh_proj* P) {
+    if (!P) return fail(BH_ERR_INVALID_ARG, "NULL bh_proj");
+    if (P->mA > 0 && !P->active_set) return fail(BH_ERR_PRECONDITION, "bh_proj_set_active has not been called (factor missing)");
+    return BH_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// exports: library / device
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* bh_strerror(int32_t code) {
+    switch (code) {
+        case BH_OK: return "ok";
+        case BH_ERR_INVALID_ARG: return "invalid argument";
+        case BH_ERR_NOT_INIT: return "library not initialised (call bh_init)";
+        case BH_ERR_HIP: return "HIP runtime error";
+        case BH_ERR_RCCL: return "RCCL error";
+        case BH_ERR_PRECONDITION: return "precondition of the reference violated";
+        case BH_ERR_SHAPE: return "shape mismatch between handles";
+        case BH_ERR_NO_DEVICE: return "no usable GPU device";
+        case BH_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error code";
+    }
+}
+
+const char* bh_last_error_detail(void) { return g_ctx.detail.c_str(); }
+
+int32_t bh_init(int32_t device, int32_t flags) {
+    if (g_ctx.init) {
+        g_ctx.flags = flags;
+        return BH_OK;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(BH_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+    if (device < 0 || device >= count) return fail(BH_ERR_INVALID_ARG, "device ordinal out of range");
+    BH_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BH_HIP(hipGetDeviceProperties(&prop, device));
+    g_ctx.n_cu = prop.multiProcessorCount;
+    g_ctx.device = device;
+    g_ctx.flags = flags;
+    BH_HIP(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
+    g_ctx.stream = g_ctx.own_stream;
+    BH_TRY(dev_alloc(&g_ctx.scratch_dev, 1024));
+    if (const char* s = getenv("BH_RS_VARIANT")) g_ctx.opt_variant = atoll(s);
+    if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = atoll(s);
+    if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(1, atoll(s));
+    g_ctx.init = true;
+    return BH_OK;
+}
+
+int32_t bh_shutdown(void) {
+    if (!g_ctx.init) return BH_OK;
+    (void)hipStreamSynchronize(g_ctx.stream);
+    if (g_ctx.comm && g_ctx.p_ncclCommDestroy) { g_ctx.p_ncclCommDestroy(g_ctx.comm); g_ctx.comm = nullptr; }
+    CgWorkspace& c = g_ctx.cg;
+    dev_free(c.slab); dev_free(c.d_state); dev_free(c.d_trace);
+    if (c.h_state) (void)hipHostFree(c.h_state);
+    if (c.ev[0]) (void)hipEventDestroy(c.ev[0]);
+    if (c.ev[1]) (void)hipEventDestroy(c.ev[1]);
+    c = CgWorkspace();
+    dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
+    if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
+    g_ctx.own_stream = nullptr; g_ctx.stream = nullptr;
+    g_ctx.init = false; g_ctx.rank = 0; g_ctx.nranks = 1;
+    return BH_OK;
+}
+
+int32_t bh_set_stream(void* hip_stream) {
+    BH_REQUIRE_INIT();
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    g_ctx.stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : g_ctx.own_stream;
+    return BH_OK;
+}
+
+int32_t bh_synchronize(void) {
+    BH_REQUIRE_INIT();
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+
+int32_t bh_device_info(char* name_out, int64_t name_cap, int32_t* n_cu, char* arch_out, int64_t arch_cap) {
+    BH_REQUIRE_INIT();
+    hipDeviceProp_t prop;
+    BH_HIP(hipGetDeviceProperties(&prop, g_ctx.device));
+    if (name_out && name_cap > 0) { strncpy(name_out, prop.name, (size_t)name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (arch_out && arch_cap > 0) { strncpy(arch_out, prop.gcnArchName, (size_t)arch_cap - 1); arch_out[arch_cap - 1] = 0; }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    return BH_OK;
+}
+
+int32_t bh_set_option(const char* key, int64_t value) {
+    if (!key) return fail(BH_ERR_INVALID_ARG, "NULL key");
+    if (!strcmp(key, "rs_variant")) { g_ctx.opt_variant = value; return BH_OK; }
+    if (!strcmp(key, "blocks_per_cu")) { g_ctx.opt_blocks_per_cu = value; return BH_OK; }
+    if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(1, value); return BH_OK; }
+    if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
+    return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------
+static int32_t load_rccl() {
+    if (g_ctx.rccl_lib) return BH_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+        g_ctx.rccl_lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (g_ctx.rccl_lib) break;
+    }
+    if (!g_ctx.rccl_lib) return fail(BH_ERR_RCCL, std::string("dlopen(librccl): ") + dlerror());
+#define BH_SYM(field, name)                                                          \
+    g_ctx.field = reinterpret_cast<decltype(g_ctx.field)>(dlsym(g_ctx.rccl_lib, name)); \
+    if (!g_ctx.field) return fail(BH_ERR_RCCL, std::string("dlsym ") + name)
+    BH_SYM(p_ncclGetUniqueId, "ncclGetUniqueId");
+    BH_SYM(p_ncclCommInitRank, "ncclCommInitRank");
+    BH_SYM(p_ncclCommDestroy, "ncclCommDestroy");
+    BH_SYM(p_ncclAllReduce, "ncclAllReduce");
+    BH_SYM(p_ncclGetErrorString, "ncclGetErrorString");
+#undef BH_SYM
+    return BH_OK;
+}
+
+int32_t bh_comm_unique_id(void* id_out) {
+    BH_REQUIRE_INIT();
+    if (!id_out) return fail(BH_ERR_INVALID_ARG, "NULL id_out");
+    static_assert(sizeof(ncclUniqueId) == BH_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    BH_TRY(load_rccl());
+    ncclUniqueId id;
+    BH_NCCL(g_ctx.p_ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return BH_OK;
+}
+
+int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id_in) {
+    BH_REQUIRE_INIT();
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(BH_ERR_INVALID_ARG, "bad rank/nranks");
+    if (g_ctx.comm) return fail(BH_ERR_INVALID_ARG, "communicator already initialised");
+    if (nranks == 1) { g_ctx.rank = 0; g_ctx.nranks = 1; return BH_OK; }
+    if (!id_in) return fail(BH_ERR_INVALID_ARG, "NULL unique id");
+    BH_TRY(load_rccl());
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    BH_NCCL(g_ctx.p_ncclCommInitRank(&g_ctx.comm, nranks, id, rank));
+    g_ctx.rank = rank;
+    g_ctx.nranks = nranks;
+    return BH_OK;
+}
+
+int32_t bh_comm_destroy(void) {
+    if (g_ctx.comm && g_ctx.p_ncclCommDestroy) {
+        (void)hipStreamSynchronize(g_ctx.stream);
+        g_ctx.p_ncclCommDestroy(g_ctx.comm);
+    }
+    g_ctx.comm = nullptr; g_ctx.rank = 0; g_ctx.nranks = 1;
+    return BH_OK;
+}
+
+int32_t bh_comm_info(int32_t* rank, int32_t* nranks) {
+    if (rank) *rank = g_ctx.rank;
+    if (nranks) *nranks = g_ctx.nranks;
+    return BH_OK;
+}
+
+// ---- AlHessian ------------------------------------------------------------------------------
+int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int64_t ldJ, const double* C, int64_t q,
+                       int64_t ldC, double mu) {
+    BH_REQUIRE_INIT();
+    if (!out) return fail(BH_ERR_INVALID_ARG, "NULL out");
+    *out = nullptr;
+    if (d < 0 || n < 1 || q < 0) return fail(BH_ERR_INVALID_ARG, "negative dimension");
+    if (d > 0 && (!J || ldJ < d)) return fail(BH_ERR_INVALID_ARG, "J NULL or ldJ < d");
+    if (q > 0 && (!C || ldC < q)) return fail(BH_ERR_INVALID_ARG, "C NULL or ldC < q");
+    bh_hess* H = new bh_hess();
+    H->d = d; H->n = n; H->q = q; H->mu = mu;
+    int32_t rc = alloc_hess_common(H);
+    if (rc == BH_OK) rc = upload_transposed(J, d, n, ldJ, H->Jd, 0, H->ld);
+    if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
+    if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    *out = H;
+    return BH_OK;
+}
+
+int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t row0, int64_t d_total, uint64_t seed,
+                                 const double* colscale, double mu) {
+    BH_REQUIRE_INIT();
+    if (!out) return fail(BH_ERR_INVALID_ARG, "NULL out");
+    *out = nullptr;
+    if (d < 1 || n < 1 || row0 < 0 || d_total < row0 + d) return fail(BH_ERR_INVALID_ARG, "bad synthetic shape");
+    bh_hess* H = new bh_hess();
+    H->d = d; H->n = n; H->q = 0; H->mu = mu;
+    int32_t rc = alloc_hess_common(H);
+    if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
+    double* cs_dev = nullptr;
+    if (colscale) {
+        rc = dev_alloc(&cs_dev, n);
+        if (rc == BH_OK && hipMemcpyAsync(cs_dev, colscale, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess)
+            rc = fail(BH_ERR_HIP, "colscale upload");
+        if (rc != BH_OK) { dev_free(cs_dev); bh_hess_destroy(H); return rc; }
+    }
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(g_ctx.n_cu * 8), dim3(256), 0, g_ctx.stream, H->Jd, H->ld, d, n, row0, d_total,
+                       seed, cs_dev, std::sqrt((double)d_total));
+    hipError_t e = hipStreamSynchronize(g_ctx.stream);
+    dev_free(cs_dev);
+    if (e != hipSuccess) { bh_hess_destroy(H); return fail(BH_ERR_HIP, std::string("synth_fill: ") + hipGetErrorString(e)); }
+    *out = H;
+    return BH_OK;
+}
+
+int32_t bh_hess_set_mu(bh_hess* H, double mu) {
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    H->mu = mu;
+    return BH_OK;
+}
+
+int32_t bh_hess_destroy(bh_hess* H) {
+    if (!H) return BH_OK;
+    if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
+    dev_free(H->Jd); dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad);
+    dev_free(H->partials); dev_free(H->sq_partials); dev_free(H->scalar);
+    for (auto e : H->ev) if (e) (void)hipEventDestroy(e);
+    delete H;
+    return BH_OK;
+}
+
+int32_t bh_hess_shape(const bh_hess* H, int64_t* d, int64_t* n, int64_t* q) {
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    if (d) *d = H->d;
+    if (n) *n = H->n;
+    if (q) *q = H->q;
+    return BH_OK;
+}
+
+static int32_t hmul_impl(bh_hess* H, const double* v, double* out, bool dev) {
+    BH_REQUIRE_INIT();
+    if (!H || !v || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(H->vpad, v, H->n, dev));
+    BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
+    BH_TRY(fetch_vec(out, H->zpad, H->n, dev));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    H->stats.n_hmul += 1;
+    return BH_OK;
+}
+int32_t bh_hmul(bh_hess* H, const double* v, double* out_n) { return hmul_impl(H, v, out_n, false); }
+int32_t bh_hmul_dev(bh_hess* H, const double* v_dev, double* out_n_dev) { return hmul_impl(H, v_dev, out_n_dev, true); }
+
+int32_t bh_vthv(bh_hess* H, const double* v, double* out_scalar) {
+    BH_REQUIRE_INIT();
+    if (!H || !v || !out_scalar) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(H->vpad, v, H->n, false));
+    BH_TRY(launch_jv(H, H->vpad, nullptr, true, H->scalar));
+    BH_TRY(allreduce_inplace(H->scalar, 1, H));
+    BH_TRY(fetch_vec(out_scalar, H->scalar, 1, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    H->stats.n_jv += 1;
+    return BH_OK;
+}
+
+static int32_t jv_impl(bh_hess* H, const double* v, double* out, bool dev) {
+    BH_REQUIRE_INIT();
+    if (!H || !v || (!out && H->d > 0)) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(H->vpad, v, H->n, dev));
+    if (dev) {
+        BH_TRY(launch_jv(H, H->vpad, out, false, nullptr));
+    } else {
+        BH_TRY(launch_jv(H, H->vpad, H->upad, false, nullptr));
+        BH_TRY(fetch_vec(out, H->upad, H->d, false));
+    }
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    H->stats.n_jv += 1;
+    return BH_OK;
+}
+int32_t bh_jv(bh_hess* H, const double* v, double* out_d) { return jv_impl(H, v, out_d, false); }
+int32_t bh_jv_dev(bh_hess* H, const double* v_dev, double* out_d_dev) { return jv_impl(H, v_dev, out_d_dev, true); }
+
+static int32_t jtv_impl(bh_hess* H, const double* u, double* out, bool dev) {
+    BH_REQUIRE_INIT();
+    if (!H || (!u && H->d > 0) || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    const double* u_dev = u;
+    if (!dev) { BH_TRY(stage_vec(H->upad, u, H->d, false)); u_dev = H->upad; }
+    BH_TRY(launch_jtv(H, u_dev, H->zpad));
+    BH_TRY(fetch_vec(out, H->zpad, H->n, dev));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    H->stats.n_jtv += 1;
+    return BH_OK;
+}
+int32_t bh_jtv(bh_hess* H, const double* u, double* out_n) { return jtv_impl(H, u, out_n, false); }
+int32_t bh_jtv_dev(bh_hess* H, const double* u_dev, double* out_n_dev) { return jtv_impl(H, u_dev, out_n_dev, true); }
+
+// ---- MixedConstraints -----------------------------------------------------------------------
+int32_t bh_proj_create(bh_proj** out, const double* A, int64_t mA, int64_t n, int64_t ldA) {
+    BH_REQUIRE_INIT();
+    if (!out) return fail(BH_ERR_INVALID_ARG, "NULL out");
+    *out = nullptr;
+    if (mA < 0 || n < 1) return fail(BH_ERR_INVALID_ARG, "negative dimension");
+    if (mA > 0 && (!A || ldA < mA)) return fail(BH_ERR_INVALID_ARG, "A NULL or ldA < mA");
+    if (mA > n) return fail(BH_ERR_PRECONDITION, "mA > n");
+    bh_proj* P = new bh_proj();
+    P->mA = mA; P->n = n; P->ldA = round_up(n, 16);
+    int32_t rc = dev_alloc(&P->Ad, std::max<int64_t>(mA, 1) * P->ldA);
+    if (rc == BH_OK) rc = dev_alloc(&P->fixrank, P->ldA);
+    if (rc == BH_OK) rc = dev_alloc(&P->fixidx, n);
+    if (rc == BH_OK) rc = dev_alloc(&P->tw, n + 16);
+    if (rc == BH_OK) rc = dev_alloc(&P->rpad, P->ldA);
+    if (rc == BH_OK) rc = dev_alloc(&P->vtmp, P->ldA);
+    if (rc == BH_OK && hipMemsetAsync(P->rpad, 0, P->ldA * sizeof(double), g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "memset");
+    if (rc == BH_OK && hipMemsetAsync(P->fixrank, 0xff, P->ldA * sizeof(int), g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "memset");
+    if (rc == BH_OK) rc = upload_transposed(A, mA, n, ldA, P->Ad, 0, P->ldA);
+    if (rc != BH_OK) { bh_proj_destroy(P); return rc; }
+    P->nfix = 0; P->mpp = (int)mA;
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    *out = P;
+    return BH_OK;
+}
+
+int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, const double* L, int64_t mpp, int64_t ldL) {
+    BH_REQUIRE_INIT();
+    if (!P) return fail(BH_ERR_INVALID_ARG, "NULL bh_proj");
+    if (n != P->n) return fail(BH_ERR_SHAPE, "fixvars length differs from n");
+    std::vector<int> rank((size_t)P->ldA, -1), idx;
+    if (fix_chunks) {
+        for (int64_t i = 0; i < n; ++i)
+            if ((fix_chunks[i >> 6] >> (i & 63)) & 1ull) { rank[(size_t)i] = (int)idx.size(); idx.push_back((int)i); }
+    }
+    const int nfix = (int)idx.size();
+    const int64_t want = P->mA + nfix;
+    if (want > n) return fail(BH_ERR_PRECONDITION, "mpp = mA + count(fixvars) > n (src/polyhedral_constraints.jl:43,128)");
+    if (P->mA > 0) {
+        if (!L) return fail(BH_ERR_INVALID_ARG, "L is required when mA > 0");
+        if (mpp != want) return fail(BH_ERR_SHAPE, "mpp != mA + count(fixvars)");
+        if (ldL < mpp) return fail(BH_ERR_INVALID_ARG, "ldL < mpp");
+        if (mpp * mpp > P->L_cap) {
+            dev_free(P->L); P->L = nullptr; P->L_cap = 0;
+            BH_TRY(dev_alloc(&P->L, mpp * mpp));
+            P->L_cap = mpp * mpp;
+        }
+        BH_HIP(hipMemcpy2DAsync(P->L, (size_t)mpp * sizeof(double), L, (size_t)ldL * sizeof(double), (size_t)mpp * sizeof(double),
+                                (size_t)mpp, hipMemcpyHostToDevice, g_ctx.stream));
+        const size_t lds = ((size_t)((mpp + 1) & ~1) + 64 * 65) * sizeof(double);
+        if (lds > 160 * 1024) return fail(BH_ERR_UNSUPPORTED, "mpp too large for the single-workgroup triangular solve");
+        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else if (mpp != want && L != nullptr) {
+        return fail(BH_ERR_SHAPE, "mpp != count(fixvars) for mA == 0");
+    }
+    BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+    if (nfix > 0) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), (size_t)nfix * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));   // host vectors go out of scope
+    P->nfix = nfix; P->mpp = (int)want; P->active_set = true;
+    return BH_OK;
+}
+
+int32_t bh_proj_destroy(bh_proj* P) {
+    if (!P) return BH_OK;
+    if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
+    dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
+    delete P;
+    return BH_OK;
+}
+
+int32_t bh_proj_shape(const bh_proj* P, int64_t* mA, int64_t* n, int64_t* n_fixed) {
+    if (!P) return fail(BH_ERR_INVALID_ARG, "NULL bh_proj");
+    if (mA) *mA = P->mA;
+    if (n) *n = P->n;
+    if (n_fixed) *n_fixed = P->nfix;
+    return BH_OK;
+}
+
+static int32_t project_impl(bh_proj* P, const double* r, double* v_out, bool dev) {
+    BH_REQUIRE_INIT();
+    BH_TRY(check_proj_ready(P));
+    if (!r || !v_out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(P->rpad, r, P->n, dev));
+    BH_TRY(launch_project(P, P->rpad, P->vtmp, nullptr));
+    BH_TRY(fetch_vec(v_out, P->vtmp, P->n, dev));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+int32_t bh_project(bh_proj* P, const double* r, double* v_out) { return project_impl(P, r, v_out, false); }
+int32_t bh_project_dev(bh_proj* P, const double* r_dev, double* v_out_dev) { return project_impl(P, r_dev, v_out_dev, true); }
+
+int32_t bh_left_mul(bh_proj* P, const double* x, double* out_mpp) {
+    BH_REQUIRE_INIT();
+    if (!P || !x || !out_mpp) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(P->rpad, x, P->n, false));
+    ProjArgs a = proj_args(P, nullptr);
+    const int grid1 = (a.mA + 3) / 4 + (a.nfix + 255) / 256;
+    if (grid1 > 0) hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, P->rpad);
+    BH_HIP(hipGetLastError());
+    BH_TRY(fetch_vec(out_mpp, P->tw, P->mA + P->nfix, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+
+int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
+    BH_REQUIRE_INIT();
+    if (!P || !y || !out_n) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(P->tw, y, P->mA + P->nfix, false));
+    ProjArgs a = proj_args(P, nullptr);
+    const int nch = ((int)P->n + 1) / 2;
+    hipLaunchKernelGGL((proj_left_mul_tr_kernel<false>), dim3((nch + 255) / 256), dim3(256), 0, g_ctx.stream, a,
+                       (const double*)nullptr, P->vtmp);
+    BH_HIP(hipGetLastError());
+    BH_TRY(fetch_vec(out_n, P->vtmp, P->n, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+
+// ---- projected_cg ---------------------------------------------------------------------------
+static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l, const double* w_u, double kappa2,
+                        double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters, double* trace,
+                        int64_t trace_cap, int32_t* n_hmul_out, bool dev) {
+    BH_REQUIRE_INIT();
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    BH_TRY(check_proj_ready(P));
+    if (!g_minor || !w_l || !w_u || !w_out) return fail(BH_ERR_INVALID_ARG, "NULL vector argument");
+    if (H->n != P->n) return fail(BH_ERR_SHAPE, "H.n != lincons.n");
+    if (trace == nullptr) trace_cap = 0;
+    if (trace_cap < 0) return fail(BH_ERR_INVALID_ARG, "negative trace_cap");
+    const int64_t n = H->n, n_pad = H->ld;
+    const int64_t max_iter64 = 2 * (n - P->mA - P->nfix);   // src/basic_tralcnlss.jl:714
+    if (max_iter64 < 0) return fail(BH_ERR_PRECONDITION, "n - mA - count(fixvars) < 0");
+    const int max_iter = (int)std::min<int64_t>(max_iter64, 0x7fffffff);
+    BH_TRY(ensure_cg_workspace(n_pad, trace_cap));
+    CgWorkspace& c = g_ctx.cg;
+    hipStream_t s = g_ctx.stream;
+
+    BH_TRY(stage_vec(c.g, g_minor, n, dev));
+    BH_TRY(stage_vec(c.wl, w_l, n, dev));
+    BH_TRY(stage_vec(c.wu, w_u, n, dev));
+
+    CgArgs a{};
+    a.st = c.d_state; a.w = c.w; a.r = c.r; a.v = c.v; a.p = c.p; a.Hp = c.Hp; a.g = c.g; a.wl = c.wl; a.wu = c.wu;
+    a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
+    a.n = (int)n; a.max_iter = max_iter; a.kappa2 = kappa2; a.atol_neg = atol_negcurv; a.atol_f2b = atol_f2b;
+    a.trace = trace_cap > 0 ? c.d_trace : nullptr; a.trace_cap = (int)std::min<int64_t>(trace_cap, 0x7fffffff);
+
+    const bool box = (P->mA == 0);
+    if (box) {
+        hipLaunchKernelGGL((cg_init_kernel<true>), dim3(1), dim3(CG_T), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((cg_init_kernel<false>), dim3(1), dim3(CG_T), 0, s, a);
+        BH_TRY(launch_project(P, c.r, c.v, c.d_state));
+        hipLaunchKernelGGL(cg_init_finish_kernel, dim3(1), dim3(CG_T), 0, s, a);
+    }
+    BH_HIP(hipGetLastError());
+
+    auto launch_iteration = [&](int index) -> int32_t {
+        BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, index));           // :722
+        if (box) {
+            hipLaunchKernelGGL((cg_step_kernel<0>), dim3(1), dim3(CG_T), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((cg_step_kernel<1>), dim3(1), dim3(CG_T), 0, s, a);
+            BH_TRY(launch_project(P, c.r, c.v, c.d_state));            // :741
+            hipLaunchKernelGGL((cg_step_kernel<2>), dim3(1), dim3(CG_T), 0, s, a);
+        }
+        return BH_OK;
+    };
+
+    // Launch-ahead loop: batch k+1 is enqueued before the host looks at batch k's state, so the GPU never
+    // waits for the host; kernels of iterations past the exit see state->done and return immediately.
+    const int batch = (int)g_ctx.opt_batch;
+    int launched = 0, k = 0;
+    auto launch_batch = [&](int slot) -> int32_t {
+        const int nb = std::min(batch, max_iter - launched);
+        for (int i = 0; i < nb; ++i) BH_TRY(launch_iteration(launched + i));
+        launched += nb;
+        BH_HIP(hipMemcpyAsync(&c.h_state[slot], c.d_state, sizeof(CgState), hipMemcpyDeviceToHost, s));
+        BH_HIP(hipEventRecord(c.ev[slot], s));
+        return BH_OK;
+    };
+    BH_TRY(launch_batch(0));
+    while (true) {
+        const bool more = launched < max_iter;
+        if (more) BH_TRY(launch_batch((k + 1) & 1));
+        BH_HIP(hipEventSynchronize(c.ev[k & 1]));
+        if (c.h_state[k & 1].done || !more) break;
+        ++k;
+    }
+    BH_HIP(hipMemcpyAsync(&c.h_state[0], c.d_state, sizeof(CgState), hipMemcpyDeviceToHost, s));
+    BH_TRY(fetch_vec(w_out, c.w, n, dev));
+    if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, s));
+    BH_HIP(hipStreamSynchronize(s));
+    const CgState fin = c.h_state[0];
+    if (!fin.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
+    if (status) *status = fin.status;
+    if (iters) *iters = fin.iter;
+    if (n_hmul_out) *n_hmul_out = fin.n_hmul;
+    H->stats.n_pcg += 1;
+    H->stats.n_hmul += fin.n_hmul;
+    H->stats.n_cg_iter += fin.iter - 1;
+    H->stats.n_proj += fin.iter;
+    if ((g_ctx.flags & BH_FLAG_PROFILE) && !H->ev.empty()) {
+        const int m = std::min(fin.n_hmul, kEvCap);
+        for (int i = 0; i < m; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, H->ev[2 * i], H->ev[2 * i + 1]) == hipSuccess) {
+                H->stats.hmul_ms += ms;
+                H->stats.hmul_timed += 1;
+            }
+        }
+    }
+    return BH_OK;
+}
+
+int32_t bh_pcg(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l, const double* w_u, double kappa2,
+               double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters, double* trace,
+               int64_t trace_cap, int32_t* n_hmul) {
+    return pcg_impl(H, P, g_minor, w_l, w_u, kappa2, atol_negcurv, atol_f2b, w_out, status, iters, trace, trace_cap, n_hmul, false);
+}
+
+int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const double* w_l_dev, const double* w_u_dev, double kappa2,
+                   double atol_negcurv, double atol_f2b, double* w_out_dev, int32_t* status, int32_t* iters, double* trace,
+                   int64_t trace_cap, int32_t* n_hmul) {
+    return pcg_impl(H, P, g_minor_dev, w_l_dev, w_u_dev, kappa2, atol_negcurv, atol_f2b, w_out_dev, status, iters, trace, trace_cap,
+                    n_hmul, true);
+}
+
+int32_t bh_factor_to_boundary(const double* p, const double* w, const double* w_l, const double* w_u, int64_t n, double atol,
+                              double* gamma_out) {
+    BH_REQUIRE_INIT();
+    if (!p || !w || !w_l || !w_u || !gamma_out || n < 0) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    double* buf = nullptr;
+    BH_TRY(dev_alloc(&buf, 4 * std::max<int64_t>(n, 1) + 1));
+    const double* src[4] = {p, w, w_l, w_u};
+    for (int i = 0; i < 4; ++i)
+        if (n > 0 && hipMemcpyAsync(buf + i * n, src[i], (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream) != hipSuccess) {
+            dev_free(buf);
+            return fail(BH_ERR_HIP, "upload");
+        }
+    hipLaunchKernelGGL(f2b_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, buf, buf + n, buf + 2 * n, buf + 3 * n, (int)n, atol, buf + 4 * n);
+    hipError_t e = hipMemcpyAsync(gamma_out, buf + 4 * n, sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_ctx.stream);
+    dev_free(buf);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("f2b: ") + hipGetErrorString(e));
+    return BH_OK;
+}
+
+// ---- plumbing -------------------------------------------------------------------------------
+int32_t bh_dev_alloc(void** out, int64_t bytes) {
+    BH_REQUIRE_INIT();
+    if (!out || bytes < 0) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    BH_HIP(hipMalloc(out, (size_t)std::max<int64_t>(bytes, 8)));
+    return BH_OK;
+}
+int32_t bh_dev_free(void* p) { dev_free(p); return BH_OK; }
+int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
+    BH_REQUIRE_INIT();
+    BH_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
+    BH_REQUIRE_INIT();
+    BH_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+
+int32_t bh_stats(bh_hess* H, bh_stats_t* out) {
+    if (!H || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    *out = H->stats;
+    return BH_OK;
+}
+int32_t bh_stats_reset(bh_hess* H) {
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    const double b = H->stats.bytes_per_hmul;
+    H->stats = bh_stats_t{};
+    H->stats.bytes_per_hmul = b;
+    return BH_OK;
+}
+
+int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
+    BH_REQUIRE_INIT();
+    if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 2) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    hipEvent_t e0, e1;
+    BH_HIP(hipEventCreate(&e0));
+    BH_HIP(hipEventCreate(&e1));
+    const int cfg = pick_config(H->nchunks);
+    RowStreamArgs a{};
+    a.J = H->Jd; a.ld = H->ld; a.d_rows = H->d; a.nchunks = H->nchunks; a.mu = H->mu; a.state = nullptr;
+    a.v = H->vpad; a.u = H->upad; a.partials = H->partials;
+    a.nrows = (kind == 0) ? H->d + H->q_eff : H->d;
+    a.t_out = (kind == 1) ? H->upad : nullptr;
+    const int mode = kind == 0 ? MODE_FUSED : (kind == 1 ? MODE_JV : MODE_JTV);
+    const int grid = grid_for(cfg, a.nrows);
+    launch_row_stream(cfg, mode, a, grid, g_ctx.stream);   // warm-up
+    double total = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        BH_HIP(hipEventRecord(e0, g_ctx.stream));
+        launch_row_stream(cfg, mode, a, grid, g_ctx.stream);
+        BH_HIP(hipEventRecord(e1, g_ctx.stream));
+        BH_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        BH_HIP(hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_ms = total / reps;
+    return BH_OK;
+}
+
+// Self-test of the wave reduction network; returns BH_OK when sum and min agree with a host computation.
+int32_t bh_selftest(void) {
+    BH_REQUIRE_INIT();
+    double host_in[256], host_out[512];
+    for (int i = 0; i < 256; ++i) host_in[i] = (double)((i * 37) % 101) - 50.0 + 1.0 / (double)(i + 3);
+    BH_HIP(hipMemcpyAsync(g_ctx.scratch_dev, host_in, sizeof(host_in), hipMemcpyHostToDevice, g_ctx.stream));
+    hipLaunchKernelGGL(selftest_wave_kernel, dim3(1), dim3(256), 0, g_ctx.stream, g_ctx.scratch_dev, g_ctx.scratch_dev + 256);
+    BH_HIP(hipMemcpyAsync(host_out, g_ctx.scratch_dev + 256, sizeof(host_out), hipMemcpyDeviceToHost, g_ctx.stream));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    for (int w = 0; w < 4; ++w) {
+        double mn = host_in[64 * w];
+        long double s = 0;
+        for (int l = 0; l < 64; ++l) { s += host_in[64 * w + l]; mn = std::min(mn, host_in[64 * w + l]); }
+        for (int l = 0; l < 64; ++l) {
+            if (std::fabs(host_out[64 * w + l] - (double)s) > 1e-11) return fail(BH_ERR_HIP, "wave_sum self-test mismatch");
+            if (host_out[64 * w + l] != host_out[64 * w]) return fail(BH_ERR_HIP, "wave_sum lanes disagree");
+            if (host_out[256 + 64 * w + l] != mn) return fail(BH_ERR_HIP, "wave_min self-test mismatch");
+        }
+    }
+    return BH_OK;
+}
+
+}  // extern "C"

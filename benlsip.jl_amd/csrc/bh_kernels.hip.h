@@ -1,0 +1,741 @@
+// bh_kernels.hip.h — hand-written gfx950 (CDNA4, wave64) kernels for the BEnlsip hot path.
+//
+// Data layout in HBM: the Jacobian block of this rank is stored ROW-MAJOR,
+// rows padded to a multiple of 16 doubles (128 B): Jd[i*ld + j].  The host hands J over
+// column-major (Julia); bh_hess_create transposes it once on the device.  Rows [d, d+q) of
+// the same image hold C, so H*p = J'(Jp) + C'(mu C p) is ONE sweep with a per-row weight.
+// Why row-major: n (<= 16384) is small enough that a whole row of J lives in the registers
+// of one workgroup (n/T doubles per lane), so J'(Jp) needs ONE read of J: the row is dotted
+// with p (wave64 DPP + permlane reduction, cross-wave through LDS), then scaled by that dot
+// and accumulated into a register-resident slice of z — 8*d*n bytes instead of 16*d*n.
+//
+// Reference call sites: src/basic_tralcnlss.jl:92-106 (vthv, *), :690-764 (projected_cg),
+// :793-809 (factor_to_boundary); src/polyhedral_constraints.jl:72-136 (left_mul, left_mul_tr,
+// projection_nullspace!, projection_subspace!).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bh {
+
+// ------------------------------------------------------------------------------------------
+// wave64 reductions: DPP inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across
+// rows (gfx950).  Butterfly form: every lane ends with the same bits (a+b == b+a).
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+// Julia's min(): NaN-propagating (src/basic_tralcnlss.jl:803,805 use min(gamma, ...)).
+struct OpMinNan {
+    __device__ __forceinline__ double operator()(double a, double b) const {
+        return (a != a) ? a : ((b != b) ? b : (a < b ? a : b));
+    }
+};
+
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double x, Op op) {
+    x = op(x, dpp_mov_f64<0xB1>(x));   // quad_perm [1,0,3,2]   lane ^ 1
+    x = op(x, dpp_mov_f64<0x4E>(x));   // quad_perm [2,3,0,1]   lane ^ 2
+    x = op(x, dpp_mov_f64<0x141>(x));  // row_half_mirror       7 - lane (mod 8)
+    x = op(x, dpp_mov_f64<0x140>(x));  // row_mirror            15 - lane (mod 16)
+    {   // rows 0<->1, 2<->3
+        unsigned lo = __double2loint(x), hi = __double2hiint(x);
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = op(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    {   // halves 0<->1
+        unsigned lo = __double2loint(x), hi = __double2hiint(x);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = op(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    return x;
+}
+__device__ __forceinline__ double wave_sum(double x) { return wave_reduce(x, OpSum()); }
+__device__ __forceinline__ double wave_min(double x) { return wave_reduce(x, OpMinNan()); }
+
+// Block-wide reduction of NV values at once; fixed combination order -> bit-reproducible.
+// `scratch` holds NV * (T/64) doubles.  Every thread returns the same totals.
+template <int T, int NV, class Op>
+__device__ __forceinline__ void block_reduce(double (&x)[NV], double* scratch, Op op, double identity) {
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) x[i] = wave_reduce(x[i], op);
+    if (NW == 1) return;
+    __syncthreads();   // scratch may still be read from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[i * NW + wave] = x[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double t = identity;
+        for (int w = 0; w < NW; ++w) t = op(t, scratch[i * NW + w]);
+        x[i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Device-resident CG state (one per bh_pcg call).  Mirrors the locals of projected_cg,
+// src/basic_tralcnlss.jl:702-718.
+// ------------------------------------------------------------------------------------------
+struct CgState {
+    double rtv, tol_cg, pHp, alpha, gamma, beta;
+    int iter;        // reference `iter` (starts at 1, :713)
+    int max_iter;    // 2*(n - mA - nfix), :714
+    int approx_solved, outside_region, neg_curvature;   // :716-718
+    int done;        // loop condition :720 is false
+    int status;      // BH_CG_*
+    int n_hmul;      // H*p products performed
+    int need_proj;   // general path: step_a decided to continue -> projection + step_b run
+    int pad;
+};
+
+// ------------------------------------------------------------------------------------------
+// Row-streaming kernel: J·v, J'·u and the fused single-read J'(W ∘ (J v)).
+//   T   threads per workgroup, CPT 16-byte chunks (2 doubles) per thread per row, R rows per step.
+//   A workgroup owns row groups g = blockIdx.x, +gridDim.x, ... (the whole grid marches through
+//   HBM together, like a copy); the next group's loads are issued before the current group's
+//   reduction so they stay in flight across the barrier.
+// ------------------------------------------------------------------------------------------
+enum { MODE_JV = 0, MODE_JTV = 1, MODE_FUSED = 2 };
+
+struct RowStreamArgs {
+    const double* J;        // row-major image, (nrows) x ld
+    int64_t ld;             // doubles per row (multiple of 16)
+    int64_t nrows;          // rows swept by this launch
+    int64_t d_rows;         // rows [0,d_rows) have weight 1, rows >= d_rows weight mu (the C block)
+    int nchunks;            // ld / 2
+    const double* v;        // n_pad doubles (JV, FUSED)
+    const double* u;        // nrows doubles (JTV)
+    double* t_out;          // nrows doubles or NULL (JV)
+    double* partials;       // gridDim.x x ld  (JTV, FUSED)
+    double* sq_partials;    // gridDim.x or NULL (JV: sum_i weight_i * t_i^2, for vthv)
+    double mu;
+    const CgState* state;   // NULL, or skip the launch when state->done
+};
+
+template <int T, int CPT, int R, int MODE>
+__global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
+    if (a.state != nullptr && a.state->done) return;
+    constexpr int NW = T / 64;
+    __shared__ double red[2][R][NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t ld2 = a.ld >> 1;   // row stride in double2
+    const double2* __restrict__ J2 = reinterpret_cast<const double2*>(a.J);
+
+    bool act[CPT];
+    double2 vv[CPT], zz[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + k * T;
+        act[k] = c < a.nchunks;
+        vv[k] = make_double2(0.0, 0.0);
+        zz[k] = make_double2(0.0, 0.0);
+        if (MODE != MODE_JTV && act[k]) vv[k] = reinterpret_cast<const double2*>(a.v)[c];
+    }
+
+    const int64_t ngroups = (a.nrows + R - 1) / R;
+    const int64_t G = gridDim.x;
+    double sq_acc = 0.0;
+    int buf = 0;
+
+    double2 A[R][CPT], B[R][CPT];
+
+    auto load_group = [&](double2 (&dst)[R][CPT], int64_t grp) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = grp * R + r;
+            const bool rv = row < a.nrows;
+            const double2* rp = J2 + (rv ? row : 0) * ld2;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                dst[r][k] = make_double2(0.0, 0.0);
+                if (rv && act[k]) dst[r][k] = rp[tid + k * T];
+            }
+        }
+    };
+
+    auto process = [&](double2 (&X)[R][CPT], int64_t grp) {
+        double s[R];
+        if (MODE != MODE_JTV) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    acc = fma(X[r][k].x, vv[k].x, acc);
+                    acc = fma(X[r][k].y, vv[k].y, acc);
+                }
+                s[r] = wave_sum(acc);
+            }
+            if (NW > 1) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) red[buf][r][wave] = s[r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) t += red[buf][r][w];
+                    s[r] = t;
+                }
+                buf ^= 1;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = grp * R + r;
+            const bool rv = row < a.nrows;
+            if (MODE == MODE_JV) {
+                if (rv) {
+                    const double wgt = (row < a.d_rows) ? 1.0 : a.mu;
+                    sq_acc = fma(wgt * s[r], s[r], sq_acc);
+                    if (a.t_out != nullptr && tid == r) a.t_out[row] = s[r];
+                }
+            } else {
+                double coef;
+                if (MODE == MODE_JTV) coef = rv ? a.u[row] : 0.0;
+                else coef = (row < a.d_rows) ? s[r] : a.mu * s[r];
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    zz[k].x = fma(coef, X[r][k].x, zz[k].x);
+                    zz[k].y = fma(coef, X[r][k].y, zz[k].y);
+                }
+            }
+        }
+    };
+
+    int64_t g = blockIdx.x;
+    if (g < ngroups) {
+        load_group(A, g);
+        while (true) {
+            int64_t gn = g + G;
+            if (gn < ngroups) load_group(B, gn);
+            process(A, g);
+            if (gn >= ngroups) break;
+            g = gn;
+            gn = g + G;
+            if (gn < ngroups) load_group(A, gn);
+            process(B, g);
+            if (gn >= ngroups) break;
+            g = gn;
+        }
+    }
+
+    if (MODE == MODE_JV) {
+        if (a.sq_partials != nullptr && tid == 0) a.sq_partials[blockIdx.x] = sq_acc;
+    } else {
+        double2* out = reinterpret_cast<double2*>(a.partials) + (int64_t)blockIdx.x * ld2;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (act[k]) out[tid + k * T] = zz[k];
+    }
+}
+
+// Sum the G partial rows written by row_stream_kernel into out (fixed order).
+// Block = 256 threads = 16 chunks x 16 row-lanes; grid = ceil(nchunks/16).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t ld,
+                                                              int nchunks, int G, double* __restrict__ out,
+                                                              const CgState* state) {
+    if (state != nullptr && state->done) return;
+    __shared__ double2 sm[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int64_t ld2 = ld >> 1;
+    const double2* P2 = reinterpret_cast<const double2*>(partials);
+    double2 acc = make_double2(0.0, 0.0);
+    if (c < nchunks) {
+        int g = rl;
+        for (; g + 48 < G; g += 64) {
+            const double2 x0 = P2[(int64_t)g * ld2 + c];
+            const double2 x1 = P2[(int64_t)(g + 16) * ld2 + c];
+            const double2 x2 = P2[(int64_t)(g + 32) * ld2 + c];
+            const double2 x3 = P2[(int64_t)(g + 48) * ld2 + c];
+            acc.x += x0.x; acc.y += x0.y;
+            acc.x += x1.x; acc.y += x1.y;
+            acc.x += x2.x; acc.y += x2.y;
+            acc.x += x3.x; acc.y += x3.y;
+        }
+        for (; g < G; g += 16) {
+            const double2 x0 = P2[(int64_t)g * ld2 + c];
+            acc.x += x0.x; acc.y += x0.y;
+        }
+    }
+    sm[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < nchunks) {
+        double2 t = sm[0][cl];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { t.x += sm[r][cl].x; t.y += sm[r][cl].y; }
+        reinterpret_cast<double2*>(out)[c] = t;
+    }
+}
+
+// Sum m doubles (single workgroup) into out[0]; used for the vthv scalar.
+__global__ __launch_bounds__(256) void reduce_scalar_kernel(const double* __restrict__ x, int m, double* out) {
+    __shared__ double scratch[4];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < m; i += 256) acc[0] += x[i];
+    block_reduce<256, 1>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+// Column-major (host layout, leading dimension lds) -> row-major padded image.  32x32 tiles via LDS.
+__global__ __launch_bounds__(256) void transpose_cm_to_rm_kernel(const double* __restrict__ src, int64_t lds_, int64_t rows,
+                                                                 int64_t cols, double* __restrict__ dst, int64_t ldd) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[r + c * lds_] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < ldd) dst[r * ldd + c] = (c < cols) ? tile[tx][ty + 8 * k] : 0.0;
+    }
+}
+
+// Synthetic Jacobian of SURVEY.md §8(d), generated in place (row-major, padded columns = 0).
+__device__ __forceinline__ double splitmix_uniform(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return __dsub_rn(__dmul_rn((double)(z >> 11), 2.0 / 9007199254740992.0), 1.0);
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(double* __restrict__ dst, int64_t ldd, int64_t rows, int64_t n,
+                                                         int64_t row0, int64_t d_total, uint64_t seed,
+                                                         const double* __restrict__ colscale, double divisor) {
+    const int64_t total = rows * ldd;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx / ldd, j = idx - i * ldd;
+        double val = 0.0;
+        if (j < n) {
+            val = __ddiv_rn(splitmix_uniform(seed, (uint64_t)(row0 + i) + (uint64_t)j * (uint64_t)d_total), divisor);
+            if (colscale != nullptr) val = __dmul_rn(val, colscale[j]);
+        }
+        dst[idx] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CG vector kernels (single workgroup of 1024 threads: n-vectors are 32 KiB at n = 4096, the
+// whole step is latency- not bandwidth-bound; one workgroup avoids any grid-level exchange).
+// Element-wise updates use separately rounded mul/add like the reference's broadcasts
+// (src/basic_tralcnlss.jl:729,737,739,740,745); dots use fma like BLAS ddot.
+// ------------------------------------------------------------------------------------------
+constexpr int CG_T = 1024;
+
+struct CgArgs {
+    CgState* st;
+    double* w; double* r; double* v; double* p;
+    const double* Hp;
+    const double* g;        // init only
+    const double* wl; const double* wu;
+    const int* fixrank;     // -1 free, else rank among fixed variables (NULL = nothing fixed)
+    int n;
+    int max_iter;
+    double kappa2, atol_neg, atol_f2b;
+    double* trace; int trace_cap;
+};
+
+__device__ __forceinline__ double f2b_term(double p, double w, double wl, double wu, double atol) {
+    // src/basic_tralcnlss.jl:802-806
+    double g = __longlong_as_double(0x7ff0000000000000ll);   // +Inf
+    if (p <= -atol) g = __ddiv_rn(__dsub_rn(wl, w), p);
+    else if (p >= atol) g = __ddiv_rn(__dsub_rn(wu, w), p);
+    return g;
+}
+
+__device__ __forceinline__ int cg_final_status(const CgState* st) {
+    // src/basic_tralcnlss.jl:753-761
+    if (st->approx_solved) return 0;
+    if (st->outside_region) return 1;
+    if (st->neg_curvature) return 2;
+    if (st->iter == st->max_iter) return 3;
+    return 4;
+}
+
+// w = 0; r = g  (:702-705).  With BOX: v = mask(r), then the tail of cg_init_finish.
+template <bool BOX>
+__global__ __launch_bounds__(CG_T) void cg_init_kernel(CgArgs a) {
+    __shared__ double scratch[2 * (CG_T / 64)];
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < a.n; i += CG_T) {
+        const double ri = a.g[i];
+        a.r[i] = ri;
+        a.w[i] = 0.0;
+        if (BOX) {
+            const double vi = (a.fixrank != nullptr && a.fixrank[i] >= 0) ? 0.0 : ri;
+            a.v[i] = vi;
+            a.p[i] = -vi;
+            acc[0] = fma(ri, vi, acc[0]);
+            acc[1] = fma(vi, vi, acc[1]);
+        }
+    }
+    if (BOX) {
+        block_reduce<CG_T, 2>(acc, scratch, OpSum(), 0.0);
+        if (threadIdx.x == 0) {
+            CgState* st = a.st;
+            st->rtv = acc[0];                       // :707
+            st->tol_cg = a.kappa2 * sqrt(acc[1]);   // :710
+            st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
+            st->iter = 1; st->max_iter = a.max_iter;
+            st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
+            st->n_hmul = 0; st->need_proj = 0;
+            st->done = (1 <= a.max_iter) ? 0 : 1;   // :720
+            st->status = cg_final_status(st);
+        }
+    } else if (threadIdx.x == 0) {
+        a.st->done = 0; a.st->need_proj = 1;
+    }
+}
+
+// General path, after v = P(r):  rtv = r.v ; p = -v ; tol_cg = kappa2*||v||  (:707-710).
+__global__ __launch_bounds__(CG_T) void cg_init_finish_kernel(CgArgs a) {
+    __shared__ double scratch[2 * (CG_T / 64)];
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < a.n; i += CG_T) {
+        const double ri = a.r[i], vi = a.v[i];
+        a.p[i] = -vi;
+        acc[0] = fma(ri, vi, acc[0]);
+        acc[1] = fma(vi, vi, acc[1]);
+    }
+    block_reduce<CG_T, 2>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) {
+        CgState* st = a.st;
+        st->rtv = acc[0];
+        st->tol_cg = a.kappa2 * sqrt(acc[1]);
+        st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
+        st->iter = 1; st->max_iter = a.max_iter;
+        st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
+        st->n_hmul = 0; st->need_proj = 0;
+        st->done = (1 <= a.max_iter) ? 0 : 1;
+        st->status = cg_final_status(st);
+    }
+}
+
+// One pass of the loop body, src/basic_tralcnlss.jl:722-750.
+//   PHASE 0 (box, fused): everything, projection = mask.
+//   PHASE 1 (general, step_a): pHp, gamma, branch, w/r update; sets need_proj.
+//   PHASE 2 (general, step_b): rtv_next, beta, p, exit test (after v = P(r)).
+template <int PHASE>
+__global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
+    __shared__ double scratch[2 * (CG_T / 64)];
+    __shared__ int s_continue;
+    CgState* st = a.st;
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+
+    double alpha = 0.0, rtv = st->rtv;
+
+    if (PHASE != 2) {
+        // pHp = dot(p,Hp) (:723) and gamma = factor_to_boundary(p,w,w_l,w_u) (:728,:734)
+        double sum[1] = {0.0};
+        double gmin[1] = {INF};
+        OpMinNan opmin;
+        for (int i = tid; i < a.n; i += CG_T) {
+            const double pi = a.p[i];
+            sum[0] = fma(pi, a.Hp[i], sum[0]);
+            gmin[0] = opmin(gmin[0], f2b_term(pi, a.w[i], a.wl[i], a.wu[i], a.atol_f2b));
+        }
+        block_reduce<CG_T, 1>(sum, scratch, OpSum(), 0.0);
+        block_reduce<CG_T, 1>(gmin, scratch, opmin, INF);
+        const double pHp = sum[0], gamma = gmin[0];
+
+        int cont = 0;        // 1: CG update (:739-748) follows
+        double step = 0.0;   // multiple of p added to w
+        int neg = 0, outside = 0;
+        if (pHp <= a.atol_neg) {                    // :725
+            neg = 1;
+            if (fabs(pHp) > a.atol_neg) step = gamma;   // :727-729
+            else step = 0.0;
+        } else {
+            alpha = __ddiv_rn(rtv, pHp);            // :733  (rtv == dot(r,v) bit for bit: deterministic dot)
+            outside = alpha > gamma;                // :735
+            if (outside) step = gamma;              // :737
+            else { step = alpha; cont = 1; }        // :739
+        }
+        const bool add_w = !(neg && !(fabs(pHp) > a.atol_neg));
+        if (add_w) {
+            for (int i = tid; i < a.n; i += CG_T) a.w[i] = __dadd_rn(a.w[i], __dmul_rn(step, a.p[i]));
+        }
+        if (tid == 0) {
+            st->pHp = pHp; st->gamma = gamma; st->alpha = (pHp <= a.atol_neg) ? __longlong_as_double(0x7ff8000000000000ll) : alpha;
+            st->n_hmul += 1;
+            st->neg_curvature = neg; st->outside_region = outside;
+            if (!cont) {
+                st->done = 1; st->need_proj = 0;
+                st->status = cg_final_status(st);
+                if (a.trace != nullptr && st->n_hmul <= a.trace_cap) {
+                    double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
+                    row[0] = pHp; row[1] = st->alpha; row[2] = (neg && !add_w) ? __longlong_as_double(0x7ff8000000000000ll) : gamma; row[3] = rtv;
+                }
+            } else {
+                st->need_proj = 1;
+            }
+            s_continue = cont;
+        }
+        __syncthreads();
+        if (!s_continue) return;
+        // r .+= alpha*Hp  (:740)
+        if (PHASE == 0) {
+            double acc[1] = {0.0};
+            for (int i = tid; i < a.n; i += CG_T) {
+                const double ri = __dadd_rn(a.r[i], __dmul_rn(alpha, a.Hp[i]));
+                a.r[i] = ri;
+                const double vi = (a.fixrank != nullptr && a.fixrank[i] >= 0) ? 0.0 : ri;   // projection!, box case (:741)
+                a.v[i] = vi;
+                acc[0] = fma(ri, vi, acc[0]);       // :743
+            }
+            block_reduce<CG_T, 1>(acc, scratch, OpSum(), 0.0);
+            const double rtv_next = acc[0];
+            const double beta = __ddiv_rn(rtv_next, rtv);       // :744
+            for (int i = tid; i < a.n; i += CG_T)
+                a.p[i] = __dadd_rn(-a.v[i], __dmul_rn(beta, a.p[i]));   // :745
+            if (tid == 0) {
+                st->beta = beta; st->rtv = rtv_next;            // :746
+                st->approx_solved = fabs(rtv_next) < st->tol_cg;   // :747
+                st->iter += 1;                                  // :748
+                st->need_proj = 0;
+                if (st->approx_solved || st->iter > st->max_iter) { st->done = 1; st->status = cg_final_status(st); }
+                if (a.trace != nullptr && st->n_hmul <= a.trace_cap) {
+                    double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
+                    row[0] = st->pHp; row[1] = alpha; row[2] = st->gamma; row[3] = rtv_next;
+                }
+            }
+        } else {
+            for (int i = tid; i < a.n; i += CG_T) a.r[i] = __dadd_rn(a.r[i], __dmul_rn(alpha, a.Hp[i]));
+        }
+    } else {
+        if (!st->need_proj) return;
+        alpha = st->alpha;
+        double acc[1] = {0.0};
+        for (int i = tid; i < a.n; i += CG_T) acc[0] = fma(a.r[i], a.v[i], acc[0]);
+        block_reduce<CG_T, 1>(acc, scratch, OpSum(), 0.0);
+        const double rtv_next = acc[0];
+        const double beta = __ddiv_rn(rtv_next, rtv);
+        for (int i = tid; i < a.n; i += CG_T) a.p[i] = __dadd_rn(-a.v[i], __dmul_rn(beta, a.p[i]));
+        if (tid == 0) {
+            st->beta = beta; st->rtv = rtv_next;
+            st->approx_solved = fabs(rtv_next) < st->tol_cg;
+            st->iter += 1;
+            st->need_proj = 0;
+            if (st->approx_solved || st->iter > st->max_iter) { st->done = 1; st->status = cg_final_status(st); }
+            if (a.trace != nullptr && st->n_hmul <= a.trace_cap) {
+                double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
+                row[0] = st->pHp; row[1] = alpha; row[2] = st->gamma; row[3] = rtv_next;
+            }
+        }
+    }
+}
+
+// Stand-alone factor_to_boundary (tests).
+__global__ __launch_bounds__(CG_T) void f2b_kernel(const double* p, const double* w, const double* wl, const double* wu,
+                                                   int n, double atol, double* out) {
+    __shared__ double scratch[CG_T / 64];
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    double gmin[1] = {INF};
+    OpMinNan opmin;
+    for (int i = threadIdx.x; i < n; i += CG_T) gmin[0] = opmin(gmin[0], f2b_term(p[i], w[i], wl[i], wu[i], atol));
+    block_reduce<CG_T, 1>(gmin, scratch, opmin, INF);
+    if (threadIdx.x == 0) out[0] = gmin[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// Projection kernels (src/polyhedral_constraints.jl:72-136).
+// ------------------------------------------------------------------------------------------
+struct ProjArgs {
+    const double* A;        // row-major mA x ldA image of lineq (NULL when mA == 0)
+    int64_t ldA;
+    int mA, n, nfix, mpp;
+    const int* fixrank;     // n   (-1 free)
+    const int* fixidx;      // nfix
+    const double* L;        // mpp x mpp column-major, lower triangle valid
+    double* tw;             // mpp workspace
+    const CgState* state;   // NULL, or skip unless (!done && need_proj)
+};
+
+__device__ __forceinline__ bool proj_skip(const CgState* st) { return st != nullptr && (st->done || !st->need_proj); }
+
+// Box-only projection: v = fixed ? 0 : r.
+__global__ __launch_bounds__(256) void proj_mask_kernel(const double* __restrict__ r, double* __restrict__ v, const int* fixrank, int n,
+                                                        const CgState* st) {
+    if (proj_skip(st)) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        v[i] = (fixrank != nullptr && fixrank[i] >= 0) ? 0.0 : r[i];
+}
+
+// left_mul: tw[0:mA] = A x (one wave per row), tw[mA+k] = x[fixidx[k]] (:86-98).
+// grid = ceil(mA/4) + ceil(nfix/256) blocks of 256.
+__global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const double* __restrict__ x) {
+    if (proj_skip(a.state)) return;
+    const int row_blocks = (a.mA + 3) / 4;
+    if ((int)blockIdx.x < row_blocks) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int row = blockIdx.x * 4 + wave;
+        if (row >= a.mA) return;
+        const double2* rp = reinterpret_cast<const double2*>(a.A + (int64_t)row * a.ldA);
+        const double2* x2 = reinterpret_cast<const double2*>(x);
+        const int nch = (int)(a.ldA >> 1);
+        double acc = 0.0;
+        for (int c = lane; c < nch; c += 64) {
+            const double2 av = rp[c], xv = x2[c];
+            acc = fma(av.x, xv.x, acc);
+            acc = fma(av.y, xv.y, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) a.tw[row] = acc;
+    } else {
+        const int k = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        if (k < a.nfix) a.tw[a.mA + k] = x[a.fixidx[k]];
+    }
+}
+
+// out = r - left_mul_tr(tw)   (:72-84, :116, :134);  with SUBTRACT=false: out = left_mul_tr(tw).
+template <bool SUBTRACT>
+__global__ __launch_bounds__(256) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
+    if (proj_skip(a.state)) return;
+    const int nch = (a.n + 1) >> 1;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nch) return;
+    double2 acc = make_double2(0.0, 0.0);
+    const double2* A2 = reinterpret_cast<const double2*>(a.A);
+    const int64_t ld2 = a.ldA >> 1;
+    for (int i = 0; i < a.mA; ++i) {
+        const double wi = a.tw[i];
+        const double2 av = A2[(int64_t)i * ld2 + c];
+        acc.x = fma(wi, av.x, acc.x);
+        acc.y = fma(wi, av.y, acc.y);
+    }
+    const int j0 = 2 * c, j1 = 2 * c + 1;
+    if (a.fixrank != nullptr) {
+        const int k0 = a.fixrank[j0];
+        if (k0 >= 0) acc.x += a.tw[a.mA + k0];
+        if (j1 < a.n) { const int k1 = a.fixrank[j1]; if (k1 >= 0) acc.y += a.tw[a.mA + k1]; }
+    }
+    if (SUBTRACT) {
+        out[j0] = r[j0] - acc.x;
+        if (j1 < a.n) out[j1] = r[j1] - acc.y;
+    } else {
+        out[j0] = acc.x;
+        if (j1 < a.n) out[j1] = acc.y;
+    }
+}
+
+// tw <- L' \ (L \ tw)   (:114-115, :132-133).  Single workgroup, 64-wide blocked substitution;
+// the diagonal block is staged through LDS (coalesced column reads, conflict-free padded tile) and
+// solved by one wave with v_readlane broadcasts; trailing updates use all 16 waves.
+// Dynamic LDS: mpp doubles (the vector) + 64*65 doubles (tile).
+__global__ __launch_bounds__(CG_T) void trsv_pair_kernel(ProjArgs a) {
+    if (proj_skip(a.state)) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = a.mpp;
+    double* x = smem;
+    double* tile = smem + ((m + 1) & ~1);    // [64][65]
+    const double* __restrict__ L = a.L;
+    const int64_t ld = m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < m; i += CG_T) x[i] = a.tw[i];
+    __syncthreads();
+
+    // ---- forward: L y = t ----
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int nb = min(64, m - j0);
+        for (int e = tid; e < 64 * 64; e += CG_T) {
+            const int rr = e & 63, cc = e >> 6;
+            tile[rr * 65 + cc] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane i owns unknown j0+i; column jj of the block is tile[i*65 + jj] (conflict-free: stride 65)
+            double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+#pragma unroll 8
+            for (int jj = 0; jj < nb; ++jj) {
+                const double ljj = tile[jj * 65 + jj];
+                const double lij = tile[lane * 65 + jj];
+                const double xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
+                                                   __builtin_amdgcn_readlane(__double2loint(xi), jj));
+                const double xj = xs / ljj;
+                if (lane == jj) xi = xj;
+                else if (lane > jj) xi = fma(-lij, xj, xi);
+            }
+            if (lane < nb) x[j0 + lane] = xi;
+        }
+        __syncthreads();
+        for (int i = j0 + nb + tid; i < m; i += CG_T) {
+            double acc = 0.0;
+            for (int jj = 0; jj < nb; ++jj) acc = fma(L[i + (int64_t)(j0 + jj) * ld], x[j0 + jj], acc);
+            x[i] -= acc;
+        }
+        __syncthreads();
+    }
+
+    // ---- backward: L' w = y ----
+    const int nblk = (m + 63) / 64;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * 64;
+        const int nb = min(64, m - j0);
+        // x[j0+c] -= sum_{k >= j0+nb} L[k, j0+c] * x[k]   (column segments are contiguous: wave per column)
+        for (int c = wave; c < nb; c += CG_T / 64) {
+            double acc = 0.0;
+            const double* col = L + (int64_t)(j0 + c) * ld;
+            for (int k = j0 + nb + lane; k < m; k += 64) acc = fma(col[k], x[k], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) x[j0 + c] -= acc;
+        }
+        for (int e = tid; e < 64 * 64; e += CG_T) {
+            const int rr = e & 63, cc = e >> 6;
+            tile[rr * 65 + cc] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane i owns unknown j0+i and needs L[jj, i] for jj > i: tile[jj*65 + i] (consecutive lanes, conflict-free)
+            double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+#pragma unroll 8
+            for (int jj = nb - 1; jj >= 0; --jj) {
+                const double ljj = tile[jj * 65 + jj];
+                const double lji = tile[jj * 65 + lane];
+                const double xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
+                                                   __builtin_amdgcn_readlane(__double2loint(xi), jj));
+                const double xj = xs / ljj;
+                if (lane == jj) xi = xj;
+                else if (lane < jj) xi = fma(-lji, xj, xi);
+            }
+            if (lane < nb) x[j0 + lane] = xi;
+        }
+        __syncthreads();
+    }
+
+    for (int i = tid; i < m; i += CG_T) a.tw[i] = x[i];
+}
+
+// Self-test of the wave reduction network (bh_selftest): out[wave] = sum, out[16 + wave] = min.
+__global__ __launch_bounds__(256) void selftest_wave_kernel(const double* in, double* out) {
+    const double x = in[threadIdx.x];
+    const double s = wave_sum(x), mn = wave_min(x);
+    out[threadIdx.x] = s;
+    out[256 + threadIdx.x] = mn;
+}
+
+}  // namespace bh

@@ -1,0 +1,374 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C ABI.
+
+The reference is Julia; its seam is dispatch on ``AlHessian`` / ``MixedConstraints`` and the function
+``projected_cg``.  With no Julia toolchain in this image the host side above the C ABI
+is written in Python with the same names, argument meaning and error behaviour, so the parity tests
+read like the reference's own tests (``test/structures.jl``).  ``julia/BEnlsipHIP.jl`` is the
+``ccall`` shim for the real package.
+
+    reference                                                   here
+    AlHessian(J, C, mu)          src/basic_tralcnlss.jl:6-10    AlHessian(J, C, mu)
+    H * v                        :102-106                       H * v   /  hmul(H, v)
+    vthv(H, v)                   :92-96                         vthv(H, v)
+    MixedConstraints(A, chol…)   src/polyhedral_constraints.jl:1-29   MixedConstraints(A, chol_L, fixed, l, u)
+    left_mul / left_mul_tr       :72-98                         left_mul / left_mul_tr
+    projection / projection!     :150-170                       projection / projection_
+    projected_cg(...)            src/basic_tralcnlss.jl:690-764 projected_cg(...)
+    factor_to_boundary(...)      :793-809                       factor_to_boundary(...)
+    CG_status                    :12                            CGStatus (+ ``none`` for Julia's `nothing`)
+
+Everything numerical runs on the GPU; there is no CPU fallback.
+"""
+import ctypes as C
+import enum
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, ptr
+
+SQRT_EPS = math.sqrt(np.finfo(np.float64).eps)
+
+
+class CGStatus(enum.IntEnum):
+    """``@enum CG_status`` (src/basic_tralcnlss.jl:12); ``none`` = the reference returning `nothing`."""
+    solved = 0
+    bound_hit = 1
+    negative_curvature = 2
+    max_iter_reached = 3
+    none = 4
+
+
+class AlHessian:
+    """Implicit Gauss-Newton Hessian ``J'J + mu C'C`` resident in HBM (src/basic_tralcnlss.jl:6-10).
+
+    ``J`` is this rank's row block (d x n); ``C`` (q x n) is replicated.  The host arrays are only read
+    during construction (the reference builds a new AlHessian whenever J changes, :46,:84).
+    """
+
+    def __init__(self, J, C=None, mu=0.0):
+        lib = _lib.lib()
+        J = np.asarray(J, dtype=np.float64)
+        if J.ndim != 2:
+            raise ValueError("J must be a matrix")
+        d, n = J.shape
+        Jf = np.asfortranarray(J)
+        if C is None:
+            C = np.zeros((0, n))
+        C = np.asarray(C, dtype=np.float64)
+        if C.ndim != 2 or C.shape[1] != n:
+            raise ValueError("C must be q x n")
+        q = C.shape[0]
+        Cf = np.asfortranarray(C)
+        self._h = C_void()
+        check(lib.bh_hess_create(_byref(self._h), ptr(Jf) if d > 0 else None, d, n, max(d, 1),
+                                 ptr(Cf) if q > 0 else None, q, max(q, 1), float(mu)), "bh_hess_create")
+        self.d, self.n, self.q = d, n, q
+        self._mu = float(mu)
+
+    @classmethod
+    def synthetic(cls, d, n, row0=0, d_total=None, seed=1, colscale=None, mu=10.0):
+        """Benchmark instance generated in HBM; see ``bh_hess_create_synthetic``."""
+        lib = _lib.lib()
+        self = cls.__new__(cls)
+        self._h = C_void()
+        d_total = d if d_total is None else d_total
+        cs = None if colscale is None else as_f64(colscale, n)
+        check(lib.bh_hess_create_synthetic(_byref(self._h), d, n, row0, d_total, seed, ptr(cs), float(mu)),
+              "bh_hess_create_synthetic")
+        self.d, self.n, self.q = d, n, 0
+        self._mu = float(mu)
+        return self
+
+    @property
+    def mu(self):
+        return self._mu
+
+    @mu.setter
+    def mu(self, value):
+        check(_lib.lib().bh_hess_set_mu(self._h, float(value)), "bh_hess_set_mu")
+        self._mu = float(value)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __mul__(self, v):
+        return hmul(self, v)
+
+    def __matmul__(self, v):
+        return hmul(self, v)
+
+    def jv(self, v):
+        """``H.J*v`` (src/basic_tralcnlss.jl:93,103)."""
+        v = as_f64(v, self.n)
+        out = np.empty(self.d)
+        check(_lib.lib().bh_jv(self._h, ptr(v), ptr(out)), "bh_jv")
+        return out
+
+    def jtv(self, u):
+        """``H.J'*u`` (src/basic_tralcnlss.jl:105; g = Jx'*rx at :45)."""
+        u = as_f64(u, self.d)
+        out = np.empty(self.n)
+        check(_lib.lib().bh_jtv(self._h, ptr(u), ptr(out)), "bh_jtv")
+        return out
+
+    def stats(self):
+        st = _lib.bh_stats_t()
+        check(_lib.lib().bh_stats(self._h, C.byref(st)), "bh_stats")
+        return {name: getattr(st, name) for name, _ in st._fields_}
+
+    def reset_stats(self):
+        check(_lib.lib().bh_stats_reset(self._h), "bh_stats_reset")
+
+    def time_kernel(self, kind, reps=20):
+        """Average hipEvent milliseconds of one launch: kind 0 = fused J'(Jp), 1 = J v, 2 = J'u."""
+        ms = C.c_double(0.0)
+        check(_lib.lib().bh_time_kernel(self._h, kind, reps, C.byref(ms)), "bh_time_kernel")
+        return ms.value
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().bh_hess_destroy(self._h)
+            self._h = C_void()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def C_void():
+    return C.c_void_p()
+
+
+def _byref(h):
+    return C.byref(h)
+
+
+def hmul(H, v):
+    """``Base.:*(H::AlHessian, v)`` — src/basic_tralcnlss.jl:102-106."""
+    v = as_f64(v, H.n)
+    out = np.empty(H.n)
+    check(_lib.lib().bh_hmul(H.handle, ptr(v), ptr(out)), "bh_hmul")
+    return out
+
+
+def vthv(H, v):
+    """``vthv(H, v)`` — src/basic_tralcnlss.jl:92-96."""
+    v = as_f64(v, H.n)
+    out = C.c_double(0.0)
+    check(_lib.lib().bh_vthv(H.handle, ptr(v), C.byref(out)), "bh_vthv")
+    return out.value
+
+
+def pack_bitvector(fixvars):
+    """Julia ``BitVector.chunks`` layout: bit i%64 of word i//64 <=> element i."""
+    f = np.asarray(fixvars, dtype=bool)
+    b = np.packbits(f, bitorder="little")
+    pad = (-b.shape[0]) % 8
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, dtype=np.uint8)])
+    if b.shape[0] == 0:
+        b = np.zeros(8, dtype=np.uint8)
+    return np.ascontiguousarray(b).view(np.uint64)
+
+
+class MixedConstraints:
+    """``MixedConstraints`` (src/polyhedral_constraints.jl:1-29): ``lineq`` (mA x n), ``xlow``, ``xupp``,
+    ``fixvars`` and the Cholesky factor ``chol`` (lower factor L of Ã Ãᵀ; only its lower triangle is read).
+
+    The factor is maintained by the caller exactly as in the reference (``cholesky_aug_aat``, ``add_active!`` …
+    stay on the host); assign ``fixvars`` / ``chol`` (or call ``set_active``) after every
+    change and the device image is refreshed before the next projection.
+    """
+
+    def __init__(self, A, chol_L=None, fixed=None, l=None, u=None):
+        lib = _lib.lib()
+        A = np.asarray(A, dtype=np.float64)
+        if A.ndim != 2:
+            raise ValueError("A must be mA x n")
+        mA, n = A.shape
+        self.lineq = A
+        self.xlow = np.full(n, -np.inf) if l is None else as_f64(l, n)
+        self.xupp = np.full(n, np.inf) if u is None else as_f64(u, n)
+        Af = np.asfortranarray(A)
+        self._h = C_void()
+        check(lib.bh_proj_create(_byref(self._h), ptr(Af) if mA > 0 else None, mA, n, max(mA, 1)), "bh_proj_create")
+        self.mA, self.n = mA, n
+        self._fixvars = np.zeros(n, dtype=bool) if fixed is None else np.asarray(fixed, dtype=bool).copy()
+        self._chol = None if chol_L is None else np.asarray(chol_L, dtype=np.float64)
+        self._dirty = True
+
+    # -- state the reference mutates between CG calls -------------------------------------
+    @property
+    def fixvars(self):
+        return self._fixvars
+
+    @fixvars.setter
+    def fixvars(self, value):
+        self._fixvars = np.asarray(value, dtype=bool)
+        self._dirty = True
+
+    @property
+    def chol(self):
+        return self._chol
+
+    @chol.setter
+    def chol(self, value):
+        self._chol = None if value is None else np.asarray(value, dtype=np.float64)
+        self._dirty = True
+
+    def set_active(self, fixvars, chol_L):
+        self._fixvars = np.asarray(fixvars, dtype=bool)
+        self._chol = None if chol_L is None else np.asarray(chol_L, dtype=np.float64)
+        self._dirty = True
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def nb_fix(self):
+        """``nb_fix`` — src/polyhedral_constraints.jl:31."""
+        return int(np.count_nonzero(self._fixvars))
+
+    @property
+    def handle(self):
+        self._sync()
+        return self._h
+
+    def _sync(self):
+        if not self._dirty:
+            return
+        chunks = pack_bitvector(self._fixvars)
+        mpp = self.mA + self.nb_fix()
+        L = None
+        ldL = max(mpp, 1)
+        if self.mA > 0:
+            if self._chol is None:
+                raise ValueError("MixedConstraints: a Cholesky factor is required when lineq has rows")
+            L = np.asfortranarray(self._chol)
+            if L.shape != (mpp, mpp):
+                raise ValueError("chol factor is %r, expected (%d, %d) = mA + count(fixvars)" % (L.shape, mpp, mpp))
+        check(_lib.lib().bh_proj_set_active(self._h, ptr(chunks), self.n, ptr(L), mpp, ldL), "bh_proj_set_active")
+        self._dirty = False
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().bh_proj_destroy(self._h)
+            self._h = C_void()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def left_mul(lincons, x):
+    """``left_mul`` — src/polyhedral_constraints.jl:86-98."""
+    x = as_f64(x, lincons.n)
+    out = np.empty(lincons.mA + lincons.nb_fix())
+    check(_lib.lib().bh_left_mul(lincons.handle, ptr(x), ptr(out)), "bh_left_mul")
+    return out
+
+
+def left_mul_tr(lincons, y):
+    """``left_mul_tr`` — src/polyhedral_constraints.jl:72-84."""
+    y = as_f64(y, lincons.mA + lincons.nb_fix())
+    out = np.empty(lincons.n)
+    check(_lib.lib().bh_left_mul_tr(lincons.handle, ptr(y), ptr(out)), "bh_left_mul_tr")
+    return out
+
+
+def projection_(lincons, r, v):
+    """``projection!(lincons, r, v)`` — src/polyhedral_constraints.jl:158-170 (writes into ``v``)."""
+    r = as_f64(r, lincons.n)
+    if not (isinstance(v, np.ndarray) and v.dtype == np.float64 and v.flags.c_contiguous and v.shape == (lincons.n,)):
+        raise ValueError("v must be a contiguous float64 vector of length n")
+    check(_lib.lib().bh_project(lincons.handle, ptr(r), ptr(v)), "bh_project")
+
+
+def projection(lincons, r):
+    """``projection(lincons, r)`` — src/polyhedral_constraints.jl:150-155."""
+    v = np.empty(lincons.n)
+    projection_(lincons, r, v)
+    return v
+
+
+def factor_to_boundary(p, w, w_l, w_u, atol=1e-10):
+    """``factor_to_boundary`` — src/basic_tralcnlss.jl:793-809."""
+    p = as_f64(p)
+    n = p.shape[0]
+    w, w_l, w_u = as_f64(w, n), as_f64(w_l, n), as_f64(w_u, n)
+    out = C.c_double(0.0)
+    check(_lib.lib().bh_factor_to_boundary(ptr(p), ptr(w), ptr(w_l), ptr(w_u), n, float(atol), C.byref(out)),
+          "bh_factor_to_boundary")
+    return out.value
+
+
+def projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, atol=SQRT_EPS, atol_f2b=1e-10, trace_cap=0, full_output=False):
+    """``projected_cg(g_minor, H, w_l, w_u, lincons, kappa2; atol)`` — src/basic_tralcnlss.jl:690-764.
+
+    Returns ``(w, status)`` like the reference; with ``full_output`` also a dict with ``iters`` (the
+    reference's ``iter`` at exit), ``n_hmul`` and ``trace`` (rows ``pHp, alpha, gamma, rtv``).
+    """
+    n = H.n
+    g = as_f64(g_minor, n)
+    wl, wu = as_f64(w_l, n), as_f64(w_u, n)
+    w = np.empty(n)
+    status, iters, n_hmul = C.c_int32(-1), C.c_int32(0), C.c_int32(0)
+    trace = np.full((trace_cap, 4), np.nan) if trace_cap > 0 else None
+    check(_lib.lib().bh_pcg(H.handle, lincons.handle, ptr(g), ptr(wl), ptr(wu), float(kappa2), float(atol), float(atol_f2b),
+                            ptr(w), C.byref(status), C.byref(iters), ptr(trace), trace_cap, C.byref(n_hmul)), "bh_pcg")
+    st = CGStatus(status.value)
+    if full_output:
+        info = {"iters": iters.value, "n_hmul": n_hmul.value,
+                "trace": None if trace is None else trace[:min(trace_cap, n_hmul.value)]}
+        return w, st, info
+    return w, st
+
+
+class DeviceVector:
+    """A float64 vector resident in HBM (plumbing for the ``*_dev`` entry points)."""
+
+    def __init__(self, n, host=None):
+        self.n = int(n)
+        self._p = C_void()
+        check(_lib.lib().bh_dev_alloc(_byref(self._p), 8 * max(self.n, 1)), "bh_dev_alloc")
+        if host is not None:
+            self.upload(host)
+
+    @property
+    def ptr(self):
+        return self._p
+
+    def upload(self, host):
+        a = as_f64(host, self.n)
+        check(_lib.lib().bh_dev_upload(self._p, ptr(a), 8 * self.n), "bh_dev_upload")
+
+    def download(self):
+        out = np.empty(self.n)
+        check(_lib.lib().bh_dev_download(ptr(out), self._p, 8 * self.n), "bh_dev_download")
+        return out
+
+    def close(self):
+        if self._p.value:
+            _lib.lib().bh_dev_free(self._p)
+            self._p = C_void()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def projected_cg_dev(g_dev, H, wl_dev, wu_dev, lincons, kappa2, w_out_dev, atol=SQRT_EPS, atol_f2b=1e-10):
+    """``bh_pcg_dev``: all vectors already in HBM (what bench.py times).  Returns (status, iters, n_hmul)."""
+    status, iters, n_hmul = C.c_int32(-1), C.c_int32(0), C.c_int32(0)
+    check(_lib.lib().bh_pcg_dev(H.handle, lincons.handle, g_dev.ptr, wl_dev.ptr, wu_dev.ptr, float(kappa2), float(atol),
+                                float(atol_f2b), w_out_dev.ptr, C.byref(status), C.byref(iters), None, 0, C.byref(n_hmul)),
+          "bh_pcg_dev")
+    return CGStatus(status.value), iters.value, n_hmul.value

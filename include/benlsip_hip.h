@@ -1,0 +1,185 @@
+/*
+ * benlsip_hip.h — C ABI of the MI355X (gfx950) backend for BEnlsip.jl's
+ * trust-region subproblem hot path.
+ *
+ * The reference (pure Julia, /root/reference) has no FFI; its seam is Julia
+ * multiple dispatch on two concrete types and one function.
+ * Every entry point below names the reference method it replaces
+ * (path:line relative to the reference root).  julia/BEnlsipHIP.jl holds the
+ * `ccall` stubs a maintainer would load next to the unchanged package
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns int32: 0 = BH_OK, negative = error (bh_strerror);
+ *     nothing throws, nothing aborts.
+ *   - host pointers are BORROWED for the duration of the call (Julia's GC pins
+ *     ccall array arguments exactly that long); anything kept is copied.
+ *   - matrices handed over by the host are COLUMN-MAJOR (Julia) with an explicit
+ *     leading dimension; indices are 0-based on the C side.
+ *   - the only arithmetic type is IEEE fp64.
+ *   - one process drives one GPU; handles are not thread-safe (the reference is
+ *     single-threaded); every export is synchronous unless its name ends _async.
+ *   - functions with the suffix _dev take DEVICE pointers (vectors already
+ *     resident in HBM; used by bench.py and by callers that keep s, g, w on the
+ *     device between calls).
+ *   - multi-GPU: rows of J are sharded over ranks (one process per GPU); each
+ *     rank passes its own row block to bh_hess_create*.  After bh_comm_init every
+ *     J'·(…) product ends in ONE RCCL all-reduce of n doubles.
+ */
+#ifndef BENLSIP_HIP_H
+#define BENLSIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------- */
+#define BH_OK                 0
+#define BH_ERR_INVALID_ARG   -1   /* NULL handle/pointer, negative size, bad leading dimension */
+#define BH_ERR_NOT_INIT      -2   /* bh_init has not been called */
+#define BH_ERR_HIP           -3   /* a HIP runtime call failed (bh_last_error_detail) */
+#define BH_ERR_RCCL          -4   /* an RCCL call failed or librccl could not be loaded */
+#define BH_ERR_PRECONDITION  -5   /* reference @assert violated: mpp <= n, mA < mpp when fixed, ... */
+#define BH_ERR_SHAPE         -6   /* handle shapes disagree (H.n != P.n, ...) */
+#define BH_ERR_NO_DEVICE     -7   /* no gfx950 device visible */
+#define BH_ERR_UNSUPPORTED   -8
+
+/* ---- CG_status — src/basic_tralcnlss.jl:12, plus Julia's `nothing` ------ */
+#define BH_CG_SOLVED              0
+#define BH_CG_BOUND_HIT           1
+#define BH_CG_NEGATIVE_CURVATURE  2
+#define BH_CG_MAX_ITER_REACHED    3
+#define BH_CG_NONE                4   /* reference returns `nothing` */
+
+/* ---- bh_init flags ------------------------------------------------------ */
+#define BH_FLAG_PROFILE   1   /* record hipEvents around every H*p launch (bh_stats) */
+
+typedef struct bh_hess bh_hess;   /* device image of AlHessian  — src/basic_tralcnlss.jl:6-10 */
+typedef struct bh_proj bh_proj;   /* device image of MixedConstraints — src/polyhedral_constraints.jl:1-7 */
+
+typedef struct bh_stats_t {
+    int64_t n_hmul;          /* H*p products executed (fused J'(Jp) launches)            */
+    int64_t n_jv;            /* stand-alone J·v launches                                 */
+    int64_t n_jtv;           /* stand-alone J'·u launches                                */
+    int64_t n_proj;          /* projections applied                                      */
+    int64_t n_pcg;           /* bh_pcg calls                                             */
+    int64_t n_cg_iter;       /* CG iterations over all bh_pcg calls                      */
+    int64_t n_allreduce;     /* RCCL all-reduces issued                                  */
+    double  hmul_ms;         /* sum of hipEvent durations of the H*p kernel (BH_FLAG_PROFILE) */
+    int64_t hmul_timed;      /* number of H*p launches contributing to hmul_ms           */
+    double  bytes_per_hmul;  /* algorithmic bytes of one H*p launch on this rank (8*(d+q)*n + 16*n) */
+} bh_stats_t;
+
+/* ---- library / device --------------------------------------------------- */
+
+/* Select HIP device `device` for this process, create the stream and workspaces. */
+int32_t bh_init(int32_t device, int32_t flags);
+int32_t bh_shutdown(void);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) for all launches; NULL restores the library stream. */
+int32_t bh_set_stream(void* hip_stream);
+int32_t bh_synchronize(void);
+const char* bh_strerror(int32_t code);
+const char* bh_last_error_detail(void);
+/* Name, CU count and arch string of the selected device (diagnostics). */
+int32_t bh_device_info(char* name_out, int64_t name_cap, int32_t* n_cu, char* arch_out, int64_t arch_cap);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) --------------------- */
+#define BH_UNIQUE_ID_BYTES 128
+/* rank 0 creates the id, the host runtime (torch.distributed, MPI, a Julia Distributed channel) broadcasts it. */
+int32_t bh_comm_unique_id(void* id_out /* BH_UNIQUE_ID_BYTES */);
+int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id /* BH_UNIQUE_ID_BYTES */);
+int32_t bh_comm_destroy(void);
+int32_t bh_comm_info(int32_t* rank, int32_t* nranks);
+
+/* ---- AlHessian ---------------------------------------------------------- */
+
+/* Replaces the constructor AlHessian(Jx,Cx,mu) at src/basic_tralcnlss.jl:46,84: uploads this
+ * rank's row block of J (d x n, column-major, leading dimension ldJ >= d) and C (q x n; may be
+ * NULL when q == 0; replicated on every rank) and lays them out for the kernels. */
+int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int64_t ldJ,
+                       const double* C, int64_t q, int64_t ldC, double mu);
+/* Benchmark constructor: rows [row0, row0+d) of the d_total x n synthetic Jacobian of SURVEY.md §8(d),
+ * element (i,j) = u(seed, i + j*d_total)/sqrt(d_total) * (colscale ? colscale[j] : 1), generated in HBM. */
+int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t row0, int64_t d_total,
+                                 uint64_t seed, const double* colscale /* n or NULL */, double mu);
+int32_t bh_hess_set_mu(bh_hess* H, double mu);
+int32_t bh_hess_destroy(bh_hess* H);
+int32_t bh_hess_shape(const bh_hess* H, int64_t* d, int64_t* n, int64_t* q);
+
+/* Base.:*(H::AlHessian, v) — src/basic_tralcnlss.jl:102-106:  out = J'(Jv) + C'(mu C v). */
+int32_t bh_hmul(bh_hess* H, const double* v, double* out_n);
+/* vthv(H,v) — src/basic_tralcnlss.jl:92-96:  ||Jv||^2 + mu ||Cv||^2. */
+int32_t bh_vthv(bh_hess* H, const double* v, double* out_scalar);
+/* H.J*v — src/basic_tralcnlss.jl:93,103 (this rank's d rows). */
+int32_t bh_jv(bh_hess* H, const double* v, double* out_d);
+/* H.J'*u — src/basic_tralcnlss.jl:105 and g = Jx'*rx at :45,:74,:893 (u = this rank's d rows; result all-reduced). */
+int32_t bh_jtv(bh_hess* H, const double* u, double* out_n);
+/* Device-pointer forms (no PCIe traffic). */
+int32_t bh_hmul_dev(bh_hess* H, const double* v_dev, double* out_n_dev);
+int32_t bh_jv_dev(bh_hess* H, const double* v_dev, double* out_d_dev);
+int32_t bh_jtv_dev(bh_hess* H, const double* u_dev, double* out_n_dev);
+
+/* ---- MixedConstraints --------------------------------------------------- */
+
+/* Replaces MixedConstraints(A, chol_aat; l, u) — src/polyhedral_constraints.jl:9-18: uploads lineq = A (mA x n,
+ * column-major, ldA >= mA; A may be NULL when mA == 0).  xlow/xupp stay on the Julia side (only the callers use them). */
+int32_t bh_proj_create(bh_proj** out, const double* A, int64_t mA, int64_t n, int64_t ldA);
+/* Must be called after every change of lincons.fixvars / lincons.chol (active_bounds!, add_active!, update_chol! —
+ * src/polyhedral_constraints.jl:62-68,203-261).  fix_chunks = BitVector.chunks (bit i%64 of word i/64 <=> variable i fixed).
+ * L = lincons.chol factor, mpp x mpp column-major, ONLY the lower triangle (i >= j) is read;
+ * mpp must equal mA + popcount(fix) (or mA when nothing is fixed).  With mA == 0 the factor is the identity and L may be NULL. */
+int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n,
+                           const double* L, int64_t mpp, int64_t ldL);
+int32_t bh_proj_destroy(bh_proj* P);
+int32_t bh_proj_shape(const bh_proj* P, int64_t* mA, int64_t* n, int64_t* n_fixed);
+/* projection!(lincons, r, v) / projection(lincons, r) — src/polyhedral_constraints.jl:150-170
+ * (projection_nullspace! :104-118 when nothing is fixed, projection_subspace! :120-136 otherwise). */
+int32_t bh_project(bh_proj* P, const double* r, double* v_out);
+int32_t bh_project_dev(bh_proj* P, const double* r_dev, double* v_out_dev);
+/* left_mul(lincons, x) — src/polyhedral_constraints.jl:86-98:  out (mpp) = [A x ; x[fixvars]]. */
+int32_t bh_left_mul(bh_proj* P, const double* x, double* out_mpp);
+/* left_mul_tr(lincons, y) — src/polyhedral_constraints.jl:72-84:  out (n) = A'y[1:mA] (+ scatter y[mA+1:end]). */
+int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n);
+
+/* ---- projected_cg -------------------------------------------------------- */
+
+/* projected_cg(g_minor, H, w_l, w_u, lincons, kappa2; atol) — src/basic_tralcnlss.jl:690-764, with
+ * factor_to_boundary — :793-809 — evaluated on the device.  The whole loop (H*p, dots, updates, projection, branch
+ * scalars, exit test) is device-resident; the host only polls a done flag.
+ *   atol_negcurv = sqrt(eps) (:697),  atol_f2b = 1e-10 (:798).
+ *   status: BH_CG_*;  iters: the reference's `iter` variable at exit (starts at 1);
+ *   trace (optional, may be NULL): row k = {pHp, alpha, gamma, rtv} of the k-th H*p product, trace_cap rows.
+ *   n_hmul (optional): number of H*p products performed. */
+int32_t bh_pcg(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l, const double* w_u,
+               double kappa2, double atol_negcurv, double atol_f2b,
+               double* w_out, int32_t* status, int32_t* iters,
+               double* trace, int64_t trace_cap, int32_t* n_hmul);
+int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const double* w_l_dev, const double* w_u_dev,
+                   double kappa2, double atol_negcurv, double atol_f2b,
+                   double* w_out_dev, int32_t* status, int32_t* iters,
+                   double* trace, int64_t trace_cap, int32_t* n_hmul);
+/* factor_to_boundary(p, w, w_l, w_u; atol) — src/basic_tralcnlss.jl:793-809, stand-alone (tests). */
+int32_t bh_factor_to_boundary(const double* p, const double* w, const double* w_l, const double* w_u,
+                              int64_t n, double atol, double* gamma_out);
+
+/* ---- plumbing ------------------------------------------------------------ */
+int32_t bh_dev_alloc(void** out, int64_t bytes);
+int32_t bh_dev_free(void* p);
+int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes);
+int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes);
+int32_t bh_stats(bh_hess* H, bh_stats_t* out);
+int32_t bh_stats_reset(bh_hess* H);
+/* Tuning knobs (kernel geometry, CG launch-ahead depth); unknown keys return BH_ERR_INVALID_ARG. */
+int32_t bh_set_option(const char* key, int64_t value);
+/* Time `reps` back-to-back launches of one kernel class with hipEvents on the launch stream.
+ * kind: 0 = fused J'(Jp), 1 = J·v, 2 = J'·u.  Returns the average milliseconds per launch. */
+int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms);
+/* Device self-test of the wave64 DPP/permlane reduction network (sum and NaN-propagating min). */
+int32_t bh_selftest(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BENLSIP_HIP_H */
