@@ -1,0 +1,90 @@
+"""CPU tests of the host logic and of the C-ABI library (load + exported symbols; no compute without a GPU)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "benlsip_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    import benlsip_jl_amd as bh
+    lib = bh.load()
+    names = _header_symbols()
+    assert len(names) >= 40
+    for name in names:
+        assert hasattr(lib, name), "include/benlsip_hip.h declares %s but the library does not export it" % name
+    assert set(bh._lib.EXPORTS) == set(names)
+    assert lib.bh_strerror(0) == b"ok"
+    assert b"HIP" in lib.bh_strerror(-3)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: without a GPU every compute entry point raises."""
+    import benlsip_jl_amd as bh
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bh.BenlsipHipError):
+        bh.init(0)
+    lib = bh.load()
+    assert lib.bh_synchronize() == -2       # BH_ERR_NOT_INIT
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "benlsip.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "benlsip_ref" not in text and "oracle/" not in text and "oracle." not in text, f
+
+
+def test_pack_bitvector_matches_julia_chunks():
+    import benlsip_jl_amd as bh
+    f = np.zeros(130, dtype=bool)
+    f[[0, 63, 64, 129]] = True
+    ch = bh.pack_bitvector(f)
+    assert ch.dtype == np.uint64 and ch.shape == (3,)
+    assert int(ch[0]) == (1 | (1 << 63)) and int(ch[1]) == 1 and int(ch[2]) == 2
+    assert bh.pack_bitvector(np.zeros(0, dtype=bool)).shape == (1,)
+
+
+def test_row_shard_partitions_rows():
+    import benlsip_jl_amd as bh
+    for d, G in [(524288, 8), (65536, 4), (10, 3), (7, 8)]:
+        ranges = [bh.row_shard(d, k, G) for k in range(G)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == d
+        for (a, b), (c, e) in zip(ranges, ranges[1:]):
+            assert b == c and b >= a
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+    assert bh.row_shard(524288, 3, 8) == (3 * 65536, 4 * 65536)
+    with pytest.raises(ValueError):
+        bh.row_shard(10, 3, 3)
+
+
+def test_cg_status_codes_match_header():
+    import benlsip_jl_amd as bh
+    text = open(os.path.join(ROOT, "include", "benlsip_hip.h")).read()
+    for name, member in [("BH_CG_SOLVED", "solved"), ("BH_CG_BOUND_HIT", "bound_hit"), ("BH_CG_NEGATIVE_CURVATURE", "negative_curvature"),
+                         ("BH_CG_MAX_ITER_REACHED", "max_iter_reached"), ("BH_CG_NONE", "none")]:
+        val = int(re.search(r"#define\s+%s\s+(-?\d+)" % name, text).group(1))
+        assert int(bh.CGStatus[member]) == val
+
+
+def test_graft_entry_build_compiles():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build()
+    import benlsip_jl_amd as bh
+    assert os.path.exists(bh.library_path())

@@ -1,0 +1,162 @@
+"""CPU tests: the NumPy oracle against every fixture the reference's own tests hold for the hot path
+ and against the committed golden files."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import benlsip_ref as R
+import sphere_problem as sp
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _hs48():
+    h = json.load(open(os.path.join(GOLD, "hs48_projection.json")))
+    A = np.array(h["A"], dtype=np.float64)
+    x = np.array(h["x"], dtype=np.float64)
+    fix = np.zeros(A.shape[1], dtype=bool)
+    fix[np.array(h["fixed_1based"]) - 1] = True
+    return A, x, fix, np.array(h["projection"], dtype=np.float64)
+
+
+def test_hs48_projection_known_answer():
+    """test/structures.jl:37-58 — the one numeric golden vector of the reference."""
+    A, x, fix, expected = _hs48()
+    L0 = R.chol_lower(A @ A.T)
+    lincons = R.make_mixed_constraints(A, L0, fix)
+    B = np.vstack([A, np.eye(5)[fix]])
+    y = np.random.default_rng(0).random(4)
+    np.testing.assert_allclose(R.left_mul_tr(lincons, y), B.T @ y, rtol=1.5e-8)      # :51
+    np.testing.assert_allclose(R.left_mul(lincons, x), B @ x, rtol=1.5e-8)           # :52
+    proj = R.projection(lincons, x)
+    Ap = A @ proj
+    assert np.all(proj[fix] <= np.finfo(float).eps) and float(Ap @ Ap) <= np.finfo(float).eps   # :55-56
+    assert np.max(np.abs(proj - expected)) <= 1e-14                                  # :57, SURVEY §8c tolerance
+
+
+def test_gauss_newton_hessian_structure():
+    """test/structures.jl:1-16 (random 5x5, property form)."""
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        n = 5
+        J, C, mu, v = rng.random((n, n)), rng.random((n, n)), rng.random(), rng.random(n)
+        H = R.AlHessian(J, C, mu)
+        H_test = J.T @ J + mu * C.T @ C
+        np.testing.assert_allclose(R.hmul(H, v), H_test @ v, rtol=1.5e-8)
+        assert R.vthv(H, v) == pytest.approx(float(v @ (H_test @ v)), rel=1.5e-8)
+
+
+def test_mixed_constraints_structure():
+    """test/structures.jl:18-35."""
+    rng = np.random.default_rng(2)
+    m, n = 3, 6
+    A = rng.random((m, n))
+    L0 = R.chol_lower(A @ A.T)
+    cons = R.make_mixed_constraints(A, L0, l=-rng.random(n), u=rng.random(n) + 1)
+    act = np.array([2, 4, 6]) - 1
+    cons.fixvars[act] = True
+    R.update_chol(cons, L0)
+    B = np.vstack([A, np.eye(n)[act]])
+    assert list(np.flatnonzero(cons.fixvars)) == list(act)
+    np.testing.assert_allclose(cons.chol_L, np.linalg.cholesky(B @ B.T), rtol=1.5e-8, atol=1e-12)
+
+
+def test_active_bounds_identification():
+    """test/structures.jl:60-78."""
+    rng = np.random.default_rng(3)
+    m, n = 3, 7
+    A = rng.random((m, n))
+    L0 = R.chol_lower(A @ A.T)
+    cons = R.make_mixed_constraints(A, L0, l=-10 * np.ones(n), u=10 * np.ones(n))
+    x = rng.random(n)
+    x[1] = -10.0
+    R.active_bounds_inplace(cons, x, L0)
+    assert cons.fixvars[1] and not cons.fixvars[np.setdiff1d(np.arange(n), [1])].any()
+    R.add_active(cons, L0, np.array([3, 5]) - 1)
+    assert cons.fixvars[[2, 4]].all()
+    R.add_active(cons, L0, 7 - 1)
+    active = np.array([2, 3, 5, 7]) - 1
+    assert cons.fixvars[active].all() and not cons.fixvars[np.setdiff1d(np.arange(n), active)].any()
+    assert cons.chol_L.shape == (m + 4, m + 4)
+
+
+def test_sphere_regression_acceptance():
+    """test/problems/sphere_regression.jl:63-65 — the three acceptance inequalities (config 1)."""
+    xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u,
+                          max_outer_iter=100, max_inner_iter=250)
+    grad = sp.jac_r(xs).T @ sp.r(xs) + sp.jac_c(xs).T @ ys
+    P = R.projection_polyhedron_small(xs - grad, sp.A, sp.b, sp.x_l, sp.x_u)
+    assert np.linalg.norm(sp.c(xs)) < R.SQRT_EPS
+    assert R.is_feasible(xs, sp.A, sp.x_l, sp.x_u, sp.b)
+    assert np.linalg.norm(xs - P) < 1e-7
+    gold = json.load(open(os.path.join(GOLD, "sphere_regression.json")))
+    np.testing.assert_allclose(xs, gold["oracle_x"], rtol=1e-9)
+
+
+def test_box_projection_degenerates_to_mask():
+    """with A = 0 x n the augmented factor is I_p and projection = masking."""
+    n = 11
+    A = np.zeros((0, n))
+    L0 = R.chol_lower(A @ A.T)
+    fix = np.zeros(n, dtype=bool)
+    fix[[0, 3, 10]] = True
+    cons = R.make_mixed_constraints(A, L0, fix)
+    np.testing.assert_array_equal(cons.chol_L, np.eye(3))
+    r = np.arange(1.0, n + 1)
+    np.testing.assert_array_equal(R.projection(cons, r), np.where(fix, 0.0, r))
+    cons0 = R.make_mixed_constraints(A, L0)
+    np.testing.assert_array_equal(R.projection(cons0, r), r)
+
+
+def test_factor_to_boundary_inf_operands():
+    """+-Inf bounds on free variables; |p| < 1e-10 entries are skipped."""
+    p = np.array([-1.0, 2.0, 1e-11, -1e-11, 0.5])
+    w = np.array([0.1, 0.2, 0.0, 0.0, 0.0])
+    wl = np.array([-np.inf, -np.inf, -1.0, -1.0, -1.0])
+    wu = np.array([np.inf, np.inf, 1.0, 1.0, 0.25])
+    assert R.factor_to_boundary(p, w, wl, wu) == 0.5
+    assert R.factor_to_boundary(p[:4], w[:4], wl[:4], wu[:4]) == np.inf
+    assert R.factor_to_boundary(np.zeros(3), np.zeros(3), -np.ones(3), np.ones(3)) == np.inf
+
+
+def test_pcg_golden_cases_reproduce():
+    """The committed projected_cg fixtures are what the oracle produces today (guards oracle drift) and cover every
+    reachable exit: solved, bound_hit, negative_curvature, `nothing` (max_iter = 0 and iterations exhausted)."""
+    cases = json.load(open(os.path.join(GOLD, "pcg_cases.json")))["cases"]
+    seen = set()
+    for c in cases:
+        d, n, q, mA, mpp = c["d"], c["n"], c["q"], c["mA"], c["mpp"]
+        J = np.array(c["J"]).reshape((d, n), order="F")
+        C = np.array(c["C"]).reshape((q, n), order="F")
+        A = np.array(c["A"]).reshape((mA, n), order="F")
+        L = np.array(c["L"]).reshape((mpp, mpp), order="F")
+        fix = np.array(c["fixvars"], dtype=bool)
+        cons = R.MixedConstraints(A, -np.ones(n), np.ones(n), fix, L)
+        g = np.array([float(x) for x in c["g"]])
+        wl = np.array([float(x) for x in c["w_l"]])
+        wu = np.array([float(x) for x in c["w_u"]])
+        w, status, iters = R.projected_cg(g, R.AlHessian(J, C, c["mu"]), wl, wu, cons, c["kappa2"])
+        assert int(status) == c["status"] and iters == c["iters"], c["name"]
+        w_gold = np.array([float(x) for x in c["w"]])
+        # CG amplifies the 1e-16 summation-order differences of J@v (C- vs F-contiguous dgemv) by ~cond(H): up to
+        # 2e-10 on these cases (measured, also vs a long-double H*p); 1e-8 normwise is the documented oracle tolerance.
+        assert np.linalg.norm(w - w_gold) <= 1e-8 * max(np.linalg.norm(w_gold), 1e-300), c["name"]
+        seen.add(int(status))
+    assert seen == {0, 1, 2, 4}       # status 3 is unreachable in the reference
+
+
+def test_status_none_when_iterations_exhausted():
+    c = [x for x in json.load(open(os.path.join(GOLD, "pcg_cases.json")))["cases"] if x["name"] == "maxiter_exhaust"][0]
+    max_iter = 2 * (c["n"] - c["mA"] - c["nfix"])
+    assert c["status"] == int(R.CGStatus.none) and c["iters"] == max_iter + 1 and c["n_hmul"] == max_iter
+
+
+def test_synthetic_generator_is_deterministic_and_sharded():
+    J = R.synthetic_J(16, 8, seed=1)
+    J2 = np.vstack([R.synthetic_J(8, 8, seed=1, row0=0, d_total=16), R.synthetic_J(8, 8, seed=1, row0=8, d_total=16)])
+    np.testing.assert_array_equal(J, J2)
+    assert np.all(np.abs(J) <= 1 / 4.0) and abs(J.mean()) < 0.1
+    u = R.splitmix_uniform(7, np.arange(4))
+    assert np.all((u >= -1) & (u < 1)) and len(set(u.tolist())) == 4

@@ -1,0 +1,357 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the golden fixtures.
+
+Tolerances (fp64, summation order differs from any BLAS so bit parity is not meaningful):
+  * one application of J v, J'u, H*v, vthv, projection:  ||y - y_ref||_2 <= 1e-12 * || |J| |v| ||_2 (resp. ||y_ref||)
+  * projected_cg: identical status and iteration count; ||w - w_ref|| <= max(1e-9, 20 x oracle rounding sensitivity) ||w_ref||
+  * HS48 known answer: max |v - [0,0,0,2,-2]| <= 1e-14
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import benlsip_ref as R
+import sphere_problem as sp
+from _util import matvec_scale, relnorm, w_tolerance
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL1 = 1e-12
+
+
+def _flt(xs):
+    return np.array([float(x) for x in xs], dtype=np.float64)
+
+
+# ----------------------------------------------------------------------------- operators
+@pytest.mark.parametrize("d,n,q", [(4, 3, 1), (1, 1, 0), (5, 5, 5), (37, 5, 2), (64, 128, 0), (300, 130, 0), (257, 129, 1),
+                                   (1000, 1024, 3), (513, 2049, 0), (256, 4096, 2), (100, 4095, 0), (130, 8000, 1),
+                                   (8192, 1024, 0), (3, 600, 0)])
+def test_matvec_parity(bh, d, n, q):
+    """AlHessian products (src/basic_tralcnlss.jl:92-106) incl. the reference's structure test (test/structures.jl:1-16)."""
+    rng = np.random.default_rng(1000 + d + n)
+    J, C, mu = rng.standard_normal((d, n)), rng.standard_normal((q, n)), 0.75
+    v, u = rng.standard_normal(n), rng.standard_normal(d)
+    H, Ho = bh.AlHessian(J, C, mu), R.AlHessian(J, C, mu)
+    assert np.linalg.norm(H.jv(v) - J @ v) <= TOL1 * matvec_scale(J, v)
+    assert np.linalg.norm(H.jtv(u) - J.T @ u) <= TOL1 * matvec_scale(J.T, u)
+    hv = H * v
+    scale = np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(v)) + mu * np.abs(C).T @ (np.abs(C) @ np.abs(v)))
+    assert np.linalg.norm(hv - R.hmul(Ho, v)) <= TOL1 * scale
+    # reference property test: H*v ≈ (J'J + mu C'C) v and vthv ≈ v'Hv at rtol sqrt(eps)
+    if n <= 2049:
+        H_test = J.T @ J + mu * C.T @ C
+        np.testing.assert_allclose(hv, H_test @ v, rtol=1.5e-8, atol=1.5e-8 * np.linalg.norm(hv))
+    assert bh.vthv(H, v) == pytest.approx(R.vthv(Ho, v), rel=1e-12)
+    H.mu = 2.5
+    Ho.mu = 2.5
+    assert np.linalg.norm(H * v - R.hmul(Ho, v)) <= TOL1 * 4 * scale
+    H.close()
+
+
+def test_matvec_is_deterministic(bh):
+    rng = np.random.default_rng(5)
+    J = rng.standard_normal((3000, 1000))
+    v = rng.standard_normal(1000)
+    H = bh.AlHessian(J, None, 1.0)
+    a, b = H * v, H * v
+    assert np.array_equal(a, b)          # two-stage fixed-order reductions, no atomics
+    H.close()
+
+
+def test_linearity_and_symmetry_at_full_size(bh):
+    """Size-independent properties at BASELINE config 3 (d=65536, n=4096; J generated in HBM):
+    H(av+bw) = aHv + bHw, v'Hw = w'Hv, v'Hv = vthv(H,v) = ||Jv||^2, and J rows check against the host generator."""
+    d, n = 65536, 4096
+    H = bh.AlHessian.synthetic(d, n, seed=1, mu=10.0)
+    rng = np.random.default_rng(7)
+    v, w = rng.standard_normal(n), rng.standard_normal(n)
+    Hv, Hw = H * v, H * w
+    lin = H * (2.0 * v - 3.0 * w)
+    assert relnorm(lin, 2.0 * Hv - 3.0 * Hw) <= 1e-12
+    assert abs(v @ Hw - w @ Hv) <= 1e-12 * abs(v @ Hw)
+    Jv = H.jv(v)
+    assert abs(v @ Hv - Jv @ Jv) <= 1e-12 * (Jv @ Jv)
+    assert bh.vthv(H, v) == pytest.approx(float(Jv @ Jv), rel=1e-12)
+    assert relnorm(H.jtv(Jv), Hv) <= 1e-12
+    rows = np.array([0, 1, 4097, 65535])
+    for i in rows:
+        Ji = R.synthetic_J(1, n, seed=1, row0=int(i), d_total=d)
+        assert abs(Jv[i] - float(Ji[0] @ v)) <= 1e-12 * float(np.abs(Ji[0]) @ np.abs(v))
+    H.close()
+
+
+# ----------------------------------------------------------------------------- projection
+def test_hs48_projection_known_answer(bh):
+    """The reference's one golden vector: test/structures.jl:37-58."""
+    h = json.load(open(os.path.join(GOLD, "hs48_projection.json")))
+    A, x = np.array(h["A"]), np.array(h["x"])
+    fix = np.zeros(5, dtype=bool)
+    fix[np.array(h["fixed_1based"]) - 1] = True
+    L_aug = R.cholesky_aug_aat(A, fix, R.chol_lower(A @ A.T))
+    cons = bh.MixedConstraints(A, L_aug, fix)
+    B = np.vstack([A, np.eye(5)[fix]])
+    y = np.random.default_rng(0).random(4)
+    np.testing.assert_allclose(bh.left_mul_tr(cons, y), B.T @ y, rtol=1.5e-8)
+    np.testing.assert_allclose(bh.left_mul(cons, x), B @ x, rtol=1.5e-8)
+    proj = bh.projection(cons, x)
+    Ap = A @ proj
+    assert np.all(proj[fix] <= np.finfo(float).eps) and float(Ap @ Ap) <= 4 * np.finfo(float).eps
+    assert np.max(np.abs(proj - np.array(h["projection"]))) <= 1e-14
+    v = np.empty(5)
+    bh.projection_(cons, x, v)
+    assert np.array_equal(v, proj)
+
+
+@pytest.mark.parametrize("n,mA,nfix", [(6, 3, 3), (7, 3, 0), (40, 5, 10), (300, 20, 150), (300, 20, 0), (130, 64, 66), (1000, 64, 512),
+                                       (513, 1, 1), (64, 0, 9), (64, 0, 0), (4096, 64, 512)])
+def test_projection_parity(bh, n, mA, nfix):
+    """projection_nullspace! / projection_subspace! (src/polyhedral_constraints.jl:104-136) incl. garbage in the unread
+    upper triangle of the factor."""
+    rng = np.random.default_rng(n + 7 * mA + nfix)
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, nfix, replace=False)] = True
+    cons_o = R.make_mixed_constraints(A, L0, fix if nfix else None)
+    L = cons_o.chol_L.copy()
+    if L.shape[0] > 1:
+        L[np.triu_indices(L.shape[0], 1)] = np.nan        # uninitialised upper triangle must never be read
+    cons = bh.MixedConstraints(A, L, fix)
+    for _ in range(2):
+        r = rng.standard_normal(n)
+        v_ref = R.projection(cons_o, r)
+        v = bh.projection(cons, r)
+        assert np.linalg.norm(v - v_ref) <= 1e-11 * np.linalg.norm(r), (n, mA, nfix)
+        if mA:
+            assert np.linalg.norm(A @ v) <= 1e-10 * np.linalg.norm(A) * np.linalg.norm(r)
+        assert np.all(v[fix] == 0.0) if mA == 0 else np.max(np.abs(v[fix]), initial=0.0) <= 1e-12 * np.linalg.norm(r)
+        # idempotence of an orthogonal projector
+        assert np.linalg.norm(bh.projection(cons, v) - v) <= 1e-11 * np.linalg.norm(r)
+
+
+def test_projection_follows_active_set_changes(bh):
+    """add_active! / active_bounds! mutate fixvars + chol between calls (src/polyhedral_constraints.jl:203-261)."""
+    rng = np.random.default_rng(11)
+    n, mA = 50, 4
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    cons_o = R.make_mixed_constraints(A, L0, l=-np.ones(n), u=np.ones(n))
+    cons = bh.MixedConstraints(A, L0, l=-np.ones(n), u=np.ones(n))
+    r = rng.standard_normal(n)
+    assert relnorm(bh.projection(cons, r), R.projection(cons_o, r)) <= 1e-12
+    for ind in ([3], [10, 11], [49]):
+        R.add_active(cons_o, L0, np.array(ind))
+        cons.set_active(cons_o.fixvars, cons_o.chol_L)
+        assert relnorm(bh.projection(cons, r), R.projection(cons_o, r)) <= 1e-11
+        assert cons.nb_fix() == R.nb_fix(cons_o)
+
+
+def test_preconditions_are_reported_not_asserted(bh):
+    A = np.random.default_rng(0).standard_normal((2, 4))
+    cons = bh.MixedConstraints(A, np.eye(2))
+    cons.set_active(np.array([True, True, True, False]), np.eye(5))       # mpp = 5 > n = 4 (:43, :128)
+    with pytest.raises(bh.BenlsipHipError) as e:
+        bh.projection(cons, np.ones(4))
+    assert e.value.code == -5
+    cons.set_active(np.array([True, False, False, False]), np.eye(2))     # factor of the wrong order
+    with pytest.raises(ValueError):
+        bh.projection(cons, np.ones(4))
+    H = bh.AlHessian(np.ones((3, 5)), None, 1.0)
+    cons4 = bh.MixedConstraints(np.zeros((0, 4)))
+    with pytest.raises(bh.BenlsipHipError) as e:
+        bh.projected_cg(np.ones(5), H, -np.ones(5), np.ones(5), cons4, 0.1)
+    assert e.value.code == -6
+
+
+# ----------------------------------------------------------------------------- factor_to_boundary
+def test_factor_to_boundary_parity(bh):
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 64, 1000, 4097):
+        p, w = rng.standard_normal(n), 0.1 * rng.standard_normal(n)
+        p[rng.random(n) < 0.3] = 1e-11
+        wl = np.where(rng.random(n) < 0.5, -np.inf, -1.0)
+        wu = np.where(rng.random(n) < 0.5, np.inf, 1.0)
+        assert bh.factor_to_boundary(p, w, wl, wu) == R.factor_to_boundary(p, w, wl, wu)
+    z = np.zeros(8)
+    assert bh.factor_to_boundary(z, z, -np.ones(8), np.ones(8)) == np.inf
+    assert bh.factor_to_boundary(np.array([-1.0]), np.array([0.0]), np.array([-np.inf]), np.array([np.inf])) == np.inf
+
+
+# ----------------------------------------------------------------------------- projected_cg
+def _load_case(c):
+    d, n, q, mA, mpp = c["d"], c["n"], c["q"], c["mA"], c["mpp"]
+    J = _flt(c["J"]).reshape((d, n), order="F")
+    C = _flt(c["C"]).reshape((q, n), order="F")
+    A = _flt(c["A"]).reshape((mA, n), order="F")
+    L = _flt(c["L"]).reshape((mpp, mpp), order="F")
+    fix = np.array(c["fixvars"], dtype=bool)
+    return J, C, A, L, fix, _flt(c["g"]), _flt(c["w_l"]), _flt(c["w_u"])
+
+
+def test_pcg_golden_fixtures(bh):
+    """Committed oracle fixtures: every reachable exit status, q>0, mA>0, p>0, odd n, n=3, max_iter=0, exhaustion."""
+    cases = json.load(open(os.path.join(GOLD, "pcg_cases.json")))["cases"]
+    for c in cases:
+        J, C, A, L, fix, g, wl, wu = _load_case(c)
+        n = c["n"]
+        H = bh.AlHessian(J, C, c["mu"])
+        cons = bh.MixedConstraints(A, L, fix)
+        w, status, info = bh.projected_cg(g, H, wl, wu, cons, c["kappa2"], trace_cap=64, full_output=True)
+        assert int(status) == c["status"], c["name"]
+        assert info["iters"] == c["iters"] and info["n_hmul"] == c["n_hmul"], c["name"]
+        w_ref = _flt(c["w"])
+        cons_o = R.MixedConstraints(A, -np.ones(n), np.ones(n), fix, L)
+        tol = w_tolerance(g, R.AlHessian(J, C, c["mu"]), wl, wu, cons_o, c["kappa2"], w_ref)
+        if c["name"] == "maxiter_exhaust":
+            tol = 1e-6      # 8 of its 14 iterations run on rounding noise (kappa2 = 0); only status/iters are pinned tightly
+        if np.all(np.isfinite(w_ref)):
+            assert np.linalg.norm(w - w_ref) <= tol * max(np.linalg.norm(w_ref), 1e-300), (c["name"], relnorm(w, w_ref), tol)
+        else:
+            assert np.array_equal(np.isnan(w), np.isnan(w_ref)) and np.array_equal(w[np.isfinite(w_ref)], w_ref[np.isfinite(w_ref)])
+        tr_ref = np.array([[float(x) for x in row] for row in c["trace"]]).reshape(-1, 4)
+        tr = info["trace"]
+        assert tr.shape == tr_ref.shape
+        if c["name"] != "maxiter_exhaust" and tr.size:
+            m = np.isfinite(tr_ref)
+            assert np.array_equal(np.isnan(tr), np.isnan(tr_ref)), c["name"]
+            np.testing.assert_allclose(tr[m], tr_ref[m], rtol=1e-6, atol=1e-10)
+        H.close()
+        cons.close()
+
+
+@pytest.mark.parametrize("d,n,q,mA,nfix,seed", [(50, 20, 0, 0, 4, 1), (200, 64, 1, 3, 10, 2), (300, 100, 0, 0, 0, 3), (512, 257, 0, 2, 30, 4),
+                                                (1024, 512, 0, 0, 64, 5), (2000, 1000, 2, 8, 100, 6), (600, 300, 0, 16, 0, 7)])
+def test_pcg_random_instances(bh, d, n, q, mA, nfix, seed):
+    rng = np.random.default_rng(seed)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, nfix, replace=False)] = True
+    cons_o = R.make_mixed_constraints(A, L0, fix if nfix else None, l=-np.ones(n), u=np.ones(n))
+    x_minor = np.clip(0.3 * rng.standard_normal(n), -0.9, 0.9)
+    x_minor[fix] = 1.0
+    g = rng.standard_normal(n)
+    w_l, w_u = R.build_step_bounds(x_minor, cons_o, 0.1 * np.linalg.norm(g))
+    Ho = R.AlHessian(J, C, 10.0)
+    w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+    H = bh.AlHessian(J, C, 10.0)
+    cons = bh.MixedConstraints(A, cons_o.chol_L, fix)
+    w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
+    assert int(status) == int(s_ref) and info["iters"] == it_ref
+    tol = w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+    assert relnorm(w, w_ref) <= tol, (relnorm(w, w_ref), tol)
+    # w stays in the null space of the active constraints (src/basic_tralcnlss.jl:681-684)
+    if mA:
+        assert np.linalg.norm(A @ w) <= 1e-9 * np.linalg.norm(A) * np.linalg.norm(w)
+    assert np.max(np.abs(w[fix]), initial=0.0) <= 1e-12 * np.linalg.norm(w)
+    H.close()
+
+
+def test_pcg_config2_synthetic_box(bh):
+    """BASELINE config 2: d=8192, n=1024, box bounds, p = n/8, J generated in HBM vs the host generator."""
+    d, n = 8192, 1024
+    J = R.synthetic_J(d, n, seed=1)
+    inst = R.synthetic_box_vectors(d, n, fix_every=8)
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    Ho = R.AlHessian(J, np.zeros((0, n)), 10.0)
+    g = J.T @ inst.r0
+    w_l, w_u = R.build_step_bounds(inst.x, cons_o, 0.1 * np.linalg.norm(g))
+    w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+    H = bh.AlHessian.synthetic(d, n, seed=1, mu=10.0)
+    assert np.linalg.norm(H.jtv(inst.r0) - g) <= 1e-12 * matvec_scale(J.T, inst.r0)
+    cons = bh.MixedConstraints(A, None, inst.fixvars, l=inst.x_l, u=inst.x_u)
+    w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
+    assert int(status) == int(s_ref) and info["iters"] == it_ref
+    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+    # ill-conditioned variant (columns scaled by 10^(-3j/n)): many iterations
+    scale = 10.0 ** (-3.0 * np.arange(n) / n)
+    Jic = R.synthetic_J(d, n, seed=1, kind=1)
+    Hic_o = R.AlHessian(Jic, np.zeros((0, n)), 10.0)
+    gic = Jic.T @ inst.r0
+    w_l, w_u = R.build_step_bounds(inst.x, cons_o, 0.1 * np.linalg.norm(gic))
+    w_ref, s_ref, it_ref = R.projected_cg(gic, Hic_o, w_l, w_u, cons_o, 1e-3)
+    Hic = bh.AlHessian.synthetic(d, n, seed=1, colscale=scale, mu=10.0)
+    w, status, info = bh.projected_cg(gic, Hic, w_l, w_u, cons, 1e-3, full_output=True)
+    assert int(status) == int(s_ref) and abs(info["iters"] - it_ref) <= 1, (info["iters"], it_ref)
+    assert relnorm(w, w_ref) <= max(1e-6, w_tolerance(gic, Hic_o, w_l, w_u, cons_o, 1e-3, w_ref))
+
+
+def test_pcg_full_size_properties(bh):
+    """BASELINE config 3 (d=65536, n=4096, box, p=512) — too large for the oracle in seconds, so size-independent
+    properties: the returned w satisfies the CG exit test it claims, lies in the null space, and reduces the model."""
+    d, n = 65536, 4096
+    H = bh.AlHessian.synthetic(d, n, seed=1, mu=10.0)
+    inst = R.synthetic_box_vectors(d, n, fix_every=8)
+    g = H.jtv(inst.r0)
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    w_l, w_u = R.build_step_bounds(inst.x, cons_o, 0.1 * np.linalg.norm(g))
+    cons = bh.MixedConstraints(A, None, inst.fixvars, l=inst.x_l, u=inst.x_u)
+    w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, trace_cap=64, full_output=True)
+    assert status == bh.CGStatus.solved and 2 <= info["iters"] <= 64
+    assert np.all(w[inst.fixvars] == 0.0)
+    v0 = np.where(inst.fixvars, 0.0, g)
+    res = np.where(inst.fixvars, 0.0, H * w + g)                 # projected residual at exit
+    assert abs(res @ res) < 0.1 * np.linalg.norm(v0) * 1.0000001  # |rtv| < kappa2*||v0|| (:710,:747)
+    assert abs(info["trace"][-1, 3] - res @ res) <= 1e-8 * max(abs(res @ res), 1e-300) + 1e-12 * (v0 @ v0)
+    q0, q1 = 0.0, 0.5 * bh.vthv(H, w) + g @ w
+    assert q1 < q0
+    w2, status2, info2 = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
+    assert np.array_equal(w, w2) and info2["iters"] == info["iters"]       # bit-reproducible
+    H.close()
+
+
+# ----------------------------------------------------------------------------- config 1 through the restated driver
+class HipOps:
+    """Backend of the oracle's restated outer iteration (tralcnllss -> ... -> minor_iterate) that routes every
+    hot-path call through the C ABI, as julia/BEnlsipHIP.jl does for the real package."""
+
+    def __init__(self, bh):
+        self.bh = bh
+        self.n_pcg = 0
+
+    def new_hessian(self, J, C, mu):
+        return self.bh.AlHessian(J, C, mu)
+
+    def hmul(self, H, v):
+        return self.bh.hmul(H, v)
+
+    def vthv(self, H, v):
+        return self.bh.vthv(H, v)
+
+    def _dev(self, lincons):
+        dev = getattr(lincons, "_dev", None)
+        if dev is None:
+            dev = self.bh.MixedConstraints(lincons.lineq, None, None, l=lincons.xlow, u=lincons.xupp)
+            lincons._dev = dev
+        dev.set_active(lincons.fixvars, lincons.chol_L)
+        return dev
+
+    def projection(self, lincons, r):
+        return self.bh.projection(self._dev(lincons), r)
+
+    def projected_cg(self, g_minor, H, w_l, w_u, lincons, kappa2):
+        self.n_pcg += 1
+        w, status = self.bh.projected_cg(g_minor, H, w_l, w_u, self._dev(lincons), kappa2)
+        return w, R.CGStatus(int(status))
+
+
+def test_sphere_regression_through_c_abi(bh):
+    """BASELINE config 1: test/problems/sphere_regression.jl with every hot-path call on the GPU; the three acceptance
+    inequalities of :63-65 and agreement with the CPU oracle's solution."""
+    ops = HipOps(bh)
+    xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u,
+                          max_outer_iter=100, max_inner_iter=250, ops=ops)
+    assert ops.n_pcg > 10
+    grad = sp.jac_r(xs).T @ sp.r(xs) + sp.jac_c(xs).T @ ys
+    P = R.projection_polyhedron_small(xs - grad, sp.A, sp.b, sp.x_l, sp.x_u)
+    assert np.linalg.norm(sp.c(xs)) < R.SQRT_EPS
+    assert R.is_feasible(xs, sp.A, sp.x_l, sp.x_u, sp.b)
+    assert np.linalg.norm(xs - P) < 1e-7
+    gold = json.load(open(os.path.join(GOLD, "sphere_regression.json")))
+    np.testing.assert_allclose(xs, gold["oracle_x"], rtol=1e-6)
