@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — PCG subproblems/s + achieved HBM GB/s of the dominant kernel, BASELINE config 3 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one complete projected_cg subproblem (bh_pcg_dev: initial projection -> CG loop -> status) on the synthetic
+dense NLS instance of SURVEY.md §8(d): J is (N*65536) x 4096 fp64, rows sharded 65536 per GPU (J generated in HBM), box
+bounds with p = 512 active, mu = 10, kappa2 = 0.1; all vectors are resident in HBM when the timed region starts.
+Weak scaling: each rank always owns a 65536 x 4096 shard (2 GiB); with N > 1 every H*p ends in one RCCL all-reduce of
+n doubles.  `value` counts one unit per rank-shard per subproblem (N units per step), so it is the whole-job aggregate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D_PER_GPU = 65536
+N_COLS = 4096
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS):
+    syn = bh.synthetic
+    d_total = d_per_gpu * world
+    lo, hi = bh.row_shard(d_total, rank, world)
+    H = bh.AlHessian.synthetic(hi - lo, n, row0=lo, d_total=d_total, seed=1, colscale=syn.column_scale(n, kind), mu=10.0)
+    x, x_l, x_u, fix = syn.box_vectors(n, fix_every=8)
+    cons = bh.MixedConstraints(np.zeros((0, n)), None, fix, l=x_l, u=x_u)
+    g = H.jtv(syn.residual_rows(lo, hi))            # g = J' r0 (row-sharded J' t + all-reduce)
+    w_l, w_u = syn.step_bounds(x, x_l, x_u, fix, syn.initial_tr(g))
+    dv = {k: bh.DeviceVector(n, v) for k, v in (("g", g), ("wl", w_l), ("wu", w_u))}
+    dv["w"] = bh.DeviceVector(n)
+    return H, cons, dv, dict(g=g, w_l=w_l, w_u=w_u, x=x, x_l=x_l, x_u=x_u, fix=fix, lo=lo, hi=hi, d_total=d_total)
+
+
+def run_steps(bh, H, cons, dv, kappa2, steps):
+    out = None
+    for _ in range(steps):
+        out = bh.projected_cg_dev(dv["g"], H, dv["wl"], dv["wu"], cons, kappa2, dv["w"])
+    return out
+
+
+def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, d_sample=8192):
+    """The oracle (NumPy restatement; OpenBLAS dgemv, the kernel family Julia's LinearAlgebra dispatches to) timed on a
+    bounded sample: rows [0, d_sample) of the same J, then scaled to the full subproblem."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import benlsip_ref as R
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    J = R.synthetic_J(d_sample, n, seed=1, kind=kind, d_total=d_full)
+    inst = R.synthetic_box_vectors(d_sample, n, fix_every=8)
+    A = np.zeros((0, n))
+    cons = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    H = R.AlHessian(J, np.zeros((0, n)), 10.0)
+    g = J.T @ inst.r0
+    w_l, w_u = R.build_step_bounds(inst.x, cons, R.initial_tr(g))
+    tr = R.CGTrace()
+    R.projected_cg(g, H, w_l, w_u, cons, kappa2, trace=tr)            # warm-up + H*p count on the sample
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        R.projected_cg(g, H, w_l, w_u, cons, kappa2)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 8.0 or reps >= 50:
+            break
+    t_sample = el / reps
+    t_hmul_sample = t_sample / max(tr.n_hmul, 1)
+    t_full = t_hmul_sample * (d_full / d_sample) * max(n_hmul_gpu, 1)
+    return {
+        "value": 1.0 / t_full, "unit": "PCG subproblems/s", "cores": int(cores), "kind": "port",
+        "sample": "oracle (NumPy/OpenBLAS) projected_cg on rows [0,%d) of the same %dx%d J (1/%d of the rows), %d repeats, "
+                  "%.1f ms per H*p on the sample; scaled x%d in rows and to the GPU run's %d H*p per subproblem"
+                  % (d_sample, d_full, n, d_full // d_sample, reps, 1e3 * t_hmul_sample, d_full // d_sample, n_hmul_gpu),
+        "ms_per_hmul_full_size": 1e3 * t_hmul_sample * (d_full / d_sample),
+        "host_gbs": 2 * 8.0 * d_sample * n / t_hmul_sample / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--variant", choices=["wc", "ic"], default="wc",
+                    help="wc: well-conditioned J (a handful of CG iterations); ic: columns scaled 10^(-3j/n) (hundreds)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import benlsip_jl_amd as bh
+    bh.init(local_rank, flags=bh._lib.BH_FLAG_PROFILE)
+    if world > 1:
+        bh.init_distributed(rank, world, bh.torch_broadcast_bytes(torch.device("cuda", local_rank)))
+
+    def barrier():
+        bh._lib.lib().bh_synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    kind = 0 if args.variant == "wc" else 1
+    kappa2 = 0.1
+    H, cons, dv, host = setup_instance(bh, rank, world, kind)
+
+    run_steps(bh, H, cons, dv, kappa2, args.warmup)
+    H.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    status, iters, n_hmul = run_steps(bh, H, cons, dv, kappa2, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = H.stats()
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    hmul_ms = st["hmul_ms"] / max(st["hmul_timed"], 1)
+    achieved = st["bytes_per_hmul"] / (hmul_ms * 1e-3) / 1e9 if hmul_ms > 0 else 0.0
+    line = {
+        "metric": "PCG subproblems/sec (dense m=65536 n=4096 fp64 per GPU) + achieved HBM GB/s",
+        "value": world * args.steps / elapsed,
+        "unit": "PCG subproblems/s (one unit = one 65536x4096 row shard of one projected_cg call)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 3 per GPU: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), box bounds, "
+                        "p=512 active, mu=10, kappa2=0.1, variant=%s; one step = one projected_cg subproblem (bh_pcg_dev), "
+                        "vectors resident in HBM" % (host["d_total"], N_COLS, D_PER_GPU, args.variant),
+            "d_total": host["d_total"], "n": N_COLS, "rows_per_gpu": D_PER_GPU, "parallelism": "row-shard x%d + 1 all-reduce(n) per H*p" % world,
+            "cg_status": status.name, "cg_iters_per_subproblem": iters - 1, "hmul_per_subproblem": n_hmul,
+        },
+        "subproblems_per_s_global": args.steps / elapsed,
+        "cg_iters_per_s": (iters - 1) * args.steps / elapsed,
+        "ms_per_cg_iteration": ms_per_step / max(n_hmul, 1),
+        "roofline": {
+            "bound": "hbm", "kernel": "row_stream_kernel<256,8,4,MODE_FUSED> (single-read J'(Jp))",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_launch": st["bytes_per_hmul"], "avg_launch_ms": hmul_ms,
+            "launches_timed": st["hmul_timed"],
+        },
+    }
+    if not args.no_extras:
+        d_loc = host["hi"] - host["lo"]
+        mv_bytes = 8.0 * d_loc * N_COLS + 8.0 * N_COLS + 8.0 * d_loc
+        ms_f, ms_jv, ms_jtv = (H.time_kernel(k, 20) for k in (0, 1, 2))
+        line["matvec"] = {
+            "jv_ms": ms_jv, "jv_gbs": mv_bytes / ms_jv / 1e6, "jv_frac": mv_bytes / ms_jv / 1e6 / HBM_PEAK_GBS,
+            "jtv_ms": ms_jtv, "jtv_gbs": mv_bytes / ms_jtv / 1e6, "jtv_frac": mv_bytes / ms_jtv / 1e6 / HBM_PEAK_GBS,
+            "fused_ms": ms_f, "fused_gbs": st["bytes_per_hmul"] / ms_f / 1e6,
+            "note": "back-to-back launches timed with hipEvents on the launch stream (bh_time_kernel), this rank's shard",
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(kind, kappa2, n_hmul)
+    elif rank == 0:
+        line["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    barrier()
+    if dist is not None:
+        bh._lib.lib().bh_comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@ the ctypes binding and the host-side mirror of the reference's operator interfac
 """
 from . import _lib, build  # noqa: F401
 from ._lib import BenlsipHipError, init, library_path, load  # noqa: F401
-from .distributed import init_distributed, row_shard  # noqa: F401
+from . import synthetic  # noqa: F401
+from .distributed import init_distributed, row_shard, torch_broadcast_bytes  # noqa: F401
 from .operators import (AlHessian, CGStatus, DeviceVector, MixedConstraints, factor_to_boundary, hmul, left_mul,  # noqa: F401
                         left_mul_tr, pack_bitvector, projected_cg, projected_cg_dev, projection, projection_, vthv)
