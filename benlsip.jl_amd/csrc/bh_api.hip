@@ -44,6 +44,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    int64_t opt_pingpong = 1;        // alternate the sweep direction of J between consecutive H*p products
     // RCCL
     void* rccl_lib = nullptr;
     ncclComm_t comm = nullptr;
@@ -167,6 +168,7 @@ int grid_for(int cfg, int64_t nrows) {
 }
 
 constexpr int kEvCap = 512;
+constexpr int kEvStride = 4;
 
 }  // namespace
 
@@ -185,6 +187,7 @@ struct bh_hess {
     double* sq_partials = nullptr; // g_cap
     double* scalar = nullptr;      // 2
     int g_cap = 0;
+    int last_n_hmul = 0;           // H*p count of the previous bh_pcg on this handle (launch schedule hint)
     bh_stats_t stats{};
     std::vector<hipEvent_t> ev;    // 2*kEvCap, created lazily
 };
@@ -239,24 +242,26 @@ int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H) {
 }
 
 // z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
-int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index) {
+int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0) {
     const int cfg = pick_config(H->nchunks);
     const int64_t nrows = H->d + H->q_eff;
     const int grid = grid_for(cfg, nrows);
     RowStreamArgs a{};
     a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
     a.v = v_pad; a.u = nullptr; a.t_out = nullptr; a.partials = H->partials; a.sq_partials = nullptr;
-    a.mu = H->mu; a.state = state;
-    const bool timed = (g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0 && ev_index < kEvCap;
+    a.mu = H->mu; a.state = state; a.reverse = reverse;
+    // BH_FLAG_PROFILE: hipEvents around every kEvStride-th H*p launch (an event pair costs ~9 us of stream time, so
+    // timing every launch would slow the loop it measures by 2.5 %).
+    const bool timed = (g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0 && (ev_index % kEvStride) == 0 && (ev_index / kEvStride) < kEvCap;
     if (timed) {
         if (H->ev.empty()) {
             H->ev.resize(2 * kEvCap, nullptr);
             for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
         }
-        BH_HIP(hipEventRecord(H->ev[2 * ev_index], g_ctx.stream));
+        BH_HIP(hipEventRecord(H->ev[2 * (ev_index / kEvStride)], g_ctx.stream));
     }
     launch_row_stream(cfg, MODE_FUSED, a, grid, g_ctx.stream);
-    if (timed) BH_HIP(hipEventRecord(H->ev[2 * ev_index + 1], g_ctx.stream));
+    if (timed) BH_HIP(hipEventRecord(H->ev[2 * (ev_index / kEvStride) + 1], g_ctx.stream));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
                        H->partials, H->ld, H->nchunks, grid, z_out, state);
     BH_HIP(hipGetLastError());
@@ -436,6 +441,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     if (const char* s = getenv("BH_RS_VARIANT")) g_ctx.opt_variant = atoll(s);
     if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = atoll(s);
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(1, atoll(s));
+    if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
     g_ctx.init = true;
     return BH_OK;
 }
@@ -485,6 +491,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "rs_variant")) { g_ctx.opt_variant = value; return BH_OK; }
     if (!strcmp(key, "blocks_per_cu")) { g_ctx.opt_blocks_per_cu = value; return BH_OK; }
     if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(1, value); return BH_OK; }
+    if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }
@@ -814,12 +821,20 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     CgWorkspace& c = g_ctx.cg;
     hipStream_t s = g_ctx.stream;
 
-    BH_TRY(stage_vec(c.g, g_minor, n, dev));
-    BH_TRY(stage_vec(c.wl, w_l, n, dev));
-    BH_TRY(stage_vec(c.wu, w_u, n, dev));
+    // Device callers with even n hand over buffers the kernels can use in place (16-byte chunk loads stay in bounds);
+    // host callers and odd n go through the zero-padded workspace.
+    const bool in_place = dev && (n % 2 == 0);
+    const double *gp = g_minor, *wlp = w_l, *wup = w_u;
+    double* wp = w_out;
+    if (!in_place) {
+        BH_TRY(stage_vec(c.g, g_minor, n, dev));
+        BH_TRY(stage_vec(c.wl, w_l, n, dev));
+        BH_TRY(stage_vec(c.wu, w_u, n, dev));
+        gp = c.g; wlp = c.wl; wup = c.wu; wp = c.w;
+    }
 
     CgArgs a{};
-    a.st = c.d_state; a.w = c.w; a.r = c.r; a.v = c.v; a.p = c.p; a.Hp = c.Hp; a.g = c.g; a.wl = c.wl; a.wu = c.wu;
+    a.st = c.d_state; a.w = wp; a.r = c.r; a.v = c.v; a.p = c.p; a.Hp = c.Hp; a.g = gp; a.wl = wlp; a.wu = wup;
     a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
     a.n = (int)n; a.max_iter = max_iter; a.kappa2 = kappa2; a.atol_neg = atol_negcurv; a.atol_f2b = atol_f2b;
     a.trace = trace_cap > 0 ? c.d_trace : nullptr; a.trace_cap = (int)std::min<int64_t>(trace_cap, 0x7fffffff);
@@ -835,9 +850,13 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     BH_HIP(hipGetLastError());
 
     auto launch_iteration = [&](int index) -> int32_t {
-        BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, index));           // :722
+        BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, index, g_ctx.opt_pingpong ? (index & 1) : 0));   // :722
         if (box) {
-            hipLaunchKernelGGL((cg_step_kernel<0>), dim3(1), dim3(CG_T), 0, s, a);
+            const int nch = (int)((n + 1) / 2);
+            if (nch <= CG_T) hipLaunchKernelGGL((cg_step_box_reg_kernel<1>), dim3(1), dim3(CG_T), 0, s, a);
+            else if (nch <= 2 * CG_T) hipLaunchKernelGGL((cg_step_box_reg_kernel<2>), dim3(1), dim3(CG_T), 0, s, a);
+            else if (nch <= 4 * CG_T) hipLaunchKernelGGL((cg_step_box_reg_kernel<4>), dim3(1), dim3(CG_T), 0, s, a);
+            else hipLaunchKernelGGL((cg_step_kernel<0>), dim3(1), dim3(CG_T), 0, s, a);
         } else {
             hipLaunchKernelGGL((cg_step_kernel<1>), dim3(1), dim3(CG_T), 0, s, a);
             BH_TRY(launch_project(P, c.r, c.v, c.d_state));            // :741
@@ -846,28 +865,35 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
         return BH_OK;
     };
 
-    // Launch-ahead loop: batch k+1 is enqueued before the host looks at batch k's state, so the GPU never
-    // waits for the host; kernels of iterations past the exit see state->done and return immediately.
+    // Launch schedule.  Kernels of iterations past the exit see state->done and return at once, so over-launching is
+    // cheap (~3 trivial kernels per iteration) but not free.  First a batch sized by the previous call on this handle
+    // (consecutive subproblems of a minor loop behave alike), then, if the loop is still running, launch-ahead batches:
+    // batch k+1 is enqueued before the host looks at batch k's state, so the GPU never waits for the host.
     const int batch = (int)g_ctx.opt_batch;
     int launched = 0, k = 0;
-    auto launch_batch = [&](int slot) -> int32_t {
-        const int nb = std::min(batch, max_iter - launched);
+    auto launch_batch = [&](int slot, int nb) -> int32_t {
+        nb = std::min(nb, max_iter - launched);
         for (int i = 0; i < nb; ++i) BH_TRY(launch_iteration(launched + i));
         launched += nb;
         BH_HIP(hipMemcpyAsync(&c.h_state[slot], c.d_state, sizeof(CgState), hipMemcpyDeviceToHost, s));
         BH_HIP(hipEventRecord(c.ev[slot], s));
         return BH_OK;
     };
-    BH_TRY(launch_batch(0));
-    while (true) {
-        const bool more = launched < max_iter;
-        if (more) BH_TRY(launch_batch((k + 1) & 1));
-        BH_HIP(hipEventSynchronize(c.ev[k & 1]));
-        if (c.h_state[k & 1].done || !more) break;
-        ++k;
+    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, 8) : std::min(batch, 2);
+    BH_TRY(launch_batch(0, first));
+    BH_HIP(hipEventSynchronize(c.ev[0]));
+    if (!c.h_state[0].done && launched < max_iter) {
+        BH_TRY(launch_batch(0, batch));
+        while (true) {
+            const bool more = launched < max_iter;
+            if (more) BH_TRY(launch_batch((k + 1) & 1, batch));
+            BH_HIP(hipEventSynchronize(c.ev[k & 1]));
+            if (c.h_state[k & 1].done || !more) break;
+            ++k;
+        }
     }
     BH_HIP(hipMemcpyAsync(&c.h_state[0], c.d_state, sizeof(CgState), hipMemcpyDeviceToHost, s));
-    BH_TRY(fetch_vec(w_out, c.w, n, dev));
+    if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
     if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, s));
     BH_HIP(hipStreamSynchronize(s));
     const CgState fin = c.h_state[0];
@@ -876,11 +902,12 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     if (iters) *iters = fin.iter;
     if (n_hmul_out) *n_hmul_out = fin.n_hmul;
     H->stats.n_pcg += 1;
+    H->last_n_hmul = fin.n_hmul;
     H->stats.n_hmul += fin.n_hmul;
     H->stats.n_cg_iter += fin.iter - 1;
     H->stats.n_proj += fin.iter;
     if ((g_ctx.flags & BH_FLAG_PROFILE) && !H->ev.empty()) {
-        const int m = std::min(fin.n_hmul, kEvCap);
+        const int m = std::min((fin.n_hmul + kEvStride - 1) / kEvStride, kEvCap);   // launches 0, 4, 8, ... that really ran
         for (int i = 0; i < m; ++i) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, H->ev[2 * i], H->ev[2 * i + 1]) == hipSuccess) {

@@ -122,6 +122,7 @@ struct RowStreamArgs {
     double* sq_partials;    // gridDim.x or NULL (JV: sum_i weight_i * t_i^2, for vthv)
     double mu;
     const CgState* state;   // NULL, or skip the launch when state->done
+    int reverse;            // sweep the row groups last-to-first (ping-pong order keeps the tail of J in the Infinity Cache)
 };
 
 template <int T, int CPT, int R, int MODE>
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     double2 A[R][CPT], B[R][CPT];
 
     auto load_group = [&](double2 (&dst)[R][CPT], int64_t grp) {
+        if (a.reverse) grp = ngroups - 1 - grp;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = grp * R + r;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     };
 
     auto process = [&](double2 (&X)[R][CPT], int64_t grp) {
+        if (a.reverse) grp = ngroups - 1 - grp;
         double s[R];
         if (MODE != MODE_JTV) {
 #pragma unroll
@@ -545,6 +548,145 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
                 double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
                 row[0] = st->pHp; row[1] = alpha; row[2] = st->gamma; row[3] = rtv_next;
             }
+        }
+    }
+}
+
+// Register-resident form of cg_step_kernel<0> (box constraints) for n <= 2*CG_T*CH: every element a thread owns is
+// loaded ONCE with 16-byte loads that are all in flight together, the whole loop body (src/basic_tralcnlss.jl:722-750)
+// runs out of registers with two block reductions, and results are stored once.  One HBM/L2 round trip instead of four.
+template <int CH>
+__global__ __launch_bounds__(CG_T) void cg_step_box_reg_kernel(CgArgs a) {
+    constexpr int NW = CG_T / 64;
+    __shared__ double scratch[2 * NW];
+    CgState* st = a.st;
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const double QNAN = __longlong_as_double(0x7ff8000000000000ll);
+    const int nch = (a.n + 1) >> 1;
+    const double rtv = st->rtv, tol_cg = st->tol_cg;
+    const int iter0 = st->iter, max_iter = st->max_iter, n_hmul0 = st->n_hmul;
+
+    bool act[CH];
+    double2 p[CH], hp[CH], w[CH], wl[CH], wu[CH], r[CH];
+    int2 fr[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = tid + k * CG_T;
+        act[k] = c < nch;
+        p[k] = hp[k] = w[k] = wl[k] = wu[k] = r[k] = make_double2(0.0, 0.0);
+        fr[k] = make_int2(-1, -1);
+        if (act[k]) {
+            p[k] = reinterpret_cast<const double2*>(a.p)[c];
+            hp[k] = reinterpret_cast<const double2*>(a.Hp)[c];
+            w[k] = reinterpret_cast<const double2*>(a.w)[c];
+            wl[k] = reinterpret_cast<const double2*>(a.wl)[c];
+            wu[k] = reinterpret_cast<const double2*>(a.wu)[c];
+            r[k] = reinterpret_cast<const double2*>(a.r)[c];
+            if (a.fixrank != nullptr) fr[k] = reinterpret_cast<const int2*>(a.fixrank)[c];
+        }
+    }
+    // pHp = dot(p,Hp) (:723); gamma = factor_to_boundary(p,w,w_l,w_u) (:728,:734).  Padding elements are zeros: no effect.
+    OpMinNan opmin;
+    double sum = 0.0, gmin = INF;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        sum = fma(p[k].x, hp[k].x, sum);
+        sum = fma(p[k].y, hp[k].y, sum);
+        gmin = opmin(gmin, f2b_term(p[k].x, w[k].x, wl[k].x, wu[k].x, a.atol_f2b));
+        gmin = opmin(gmin, f2b_term(p[k].y, w[k].y, wl[k].y, wu[k].y, a.atol_f2b));
+    }
+    sum = wave_sum(sum);
+    gmin = wave_min(gmin);
+    if (lane == 0) { scratch[wave] = sum; scratch[NW + wave] = gmin; }
+    __syncthreads();
+    double pHp = 0.0, gamma = INF;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { pHp += scratch[i]; gamma = opmin(gamma, scratch[NW + i]); }
+    __syncthreads();   // scratch is reused below
+
+    int cont = 0, neg = 0, outside = 0;
+    double step = 0.0, alpha = QNAN;
+    bool add_w = true;
+    if (pHp <= a.atol_neg) {                        // :725
+        neg = 1;
+        if (fabs(pHp) > a.atol_neg) step = gamma;   // :727-729
+        else add_w = false;
+    } else {
+        alpha = __ddiv_rn(rtv, pHp);                // :733
+        outside = alpha > gamma;                    // :735
+        if (outside) step = gamma;                  // :737
+        else { step = alpha; cont = 1; }            // :739
+    }
+    if (add_w) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            w[k].x = __dadd_rn(w[k].x, __dmul_rn(step, p[k].x));
+            w[k].y = __dadd_rn(w[k].y, __dmul_rn(step, p[k].y));
+        }
+    }
+    double rtv_next = rtv, beta = 0.0;
+    double2 v[CH];
+    if (cont) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            r[k].x = __dadd_rn(r[k].x, __dmul_rn(alpha, hp[k].x));     // :740
+            r[k].y = __dadd_rn(r[k].y, __dmul_rn(alpha, hp[k].y));
+            v[k].x = (fr[k].x >= 0) ? 0.0 : r[k].x;                    // projection!, box case (:741)
+            v[k].y = (fr[k].y >= 0) ? 0.0 : r[k].y;
+            acc = fma(r[k].x, v[k].x, acc);                            // :743
+            acc = fma(r[k].y, v[k].y, acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) scratch[wave] = acc;
+        __syncthreads();
+        rtv_next = 0.0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) rtv_next += scratch[i];
+        beta = __ddiv_rn(rtv_next, rtv);                               // :744
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            p[k].x = __dadd_rn(-v[k].x, __dmul_rn(beta, p[k].x));      // :745
+            p[k].y = __dadd_rn(-v[k].y, __dmul_rn(beta, p[k].y));
+        }
+    }
+    // stores (never beyond n: w += Inf*0 would poison the padding)
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int c = tid + k * CG_T;
+        if (!act[k]) continue;
+        const bool full = (2 * c + 1) < a.n;
+        if (full) {
+            if (add_w) reinterpret_cast<double2*>(a.w)[c] = w[k];
+            if (cont) {
+                reinterpret_cast<double2*>(a.r)[c] = r[k];
+                reinterpret_cast<double2*>(a.v)[c] = v[k];
+                reinterpret_cast<double2*>(a.p)[c] = p[k];
+            }
+        } else {
+            if (add_w) a.w[2 * c] = w[k].x;
+            if (cont) { a.r[2 * c] = r[k].x; a.v[2 * c] = v[k].x; a.p[2 * c] = p[k].x; }
+        }
+    }
+    if (tid == 0) {
+        const int n_hmul = n_hmul0 + 1;
+        st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = n_hmul;
+        st->neg_curvature = neg; st->outside_region = outside; st->need_proj = 0;
+        double tr_gamma = (neg && !add_w) ? QNAN : gamma;
+        if (!cont) {
+            st->done = 1;
+            st->status = cg_final_status(st);
+        } else {
+            st->beta = beta; st->rtv = rtv_next;                       // :746
+            st->approx_solved = fabs(rtv_next) < tol_cg;               // :747
+            st->iter = iter0 + 1;                                      // :748
+            if (st->approx_solved || st->iter > max_iter) { st->done = 1; st->status = cg_final_status(st); }
+        }
+        if (a.trace != nullptr && n_hmul <= a.trace_cap) {
+            double* row = a.trace + 4 * (int64_t)(n_hmul - 1);
+            row[0] = pHp; row[1] = alpha; row[2] = tr_gamma; row[3] = rtv_next;
         }
     }
 }
