@@ -40,6 +40,20 @@ def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS):
     return H, cons, dv, dict(g=g, w_l=w_l, w_u=w_u, x=x, x_l=x_l, x_u=x_u, fix=fix, lo=lo, hi=hi, d_total=d_total)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json,
+    produced by tools/profile_round.sh + tools/summarize_profile.py; gfx950 FETCH_SIZE half-count already corrected)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for name, e in data.get("kernels", {}).items():
+        if "row_stream_kernel<256, 8, 4, 2" in name and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def run_steps(bh, H, cons, dv, kappa2, steps):
     out = None
     for _ in range(steps):
@@ -141,6 +155,7 @@ def main():
         elapsed = float(t.item())
     st = H.stats()
 
+    traffic, traffic_src = pmc_traffic() if world == 1 else (None, None)
     ms_per_step = 1e3 * elapsed / args.steps
     hmul_ms = st["hmul_ms"] / max(st["hmul_timed"], 1)
     achieved = st["bytes_per_hmul"] / (hmul_ms * 1e-3) / 1e9 if hmul_ms > 0 else 0.0
@@ -161,9 +176,10 @@ def main():
         "cg_iters_per_s": (iters - 1) * args.steps / elapsed,
         "ms_per_cg_iteration": ms_per_step / max(n_hmul, 1),
         "roofline": {
-            "bound": "hbm", "kernel": "row_stream_kernel<256,8,4,MODE_FUSED> (single-read J'(Jp))",
+            "bound": "hbm", "kernel": "row_stream_kernel<256,8,4,MODE_FUSED,NT> (single-read J'(Jp), non-temporal loads)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_launch": st["bytes_per_hmul"], "avg_launch_ms": hmul_ms,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": st["bytes_per_hmul"], "avg_launch_ms": hmul_ms,
             "launches_timed": st["hmul_timed"],
         },
     }

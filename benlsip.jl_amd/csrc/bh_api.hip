@@ -44,7 +44,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
-    int64_t opt_pingpong = 1;        // alternate the sweep direction of J between consecutive H*p products
+    int64_t opt_pingpong = 0;        // alternate the sweep direction of J between consecutive H*p products (A/B: +1 % without nt loads, -0.2 % with)
     // RCCL
     void* rccl_lib = nullptr;
     ncclComm_t comm = nullptr;
@@ -114,6 +114,7 @@ const RsConfig kRsConfigs[] = {
     {256, 8, 2, 1},    // 7: nchunks <= 2048  variant 2
     {1024, 2, 4, 1},   // 8: nchunks <= 2048  variant 3
     {512, 4, 2, 1},    // 9: nchunks <= 2048  variant 4
+    {256, 8, 4, 1},    // 10: nchunks <= 2048 variant 5 = variant 0 WITHOUT non-temporal loads of J (A/B: nt = +10 %)
 };
 constexpr int64_t kMaxChunks = 4096;
 
@@ -128,18 +129,19 @@ int pick_config(int nchunks) {
             case 2: return 7;
             case 3: return 8;
             case 4: return 9;
+            case 5: return 10;
             default: return 4;
         }
     }
     return 5;
 }
 
-template <int T, int CPT, int R>
+template <int T, int CPT, int R, int NT = 1>
 void launch_rs_mode(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
     switch (mode) {
-        case MODE_JV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JV>), dim3(grid), dim3(T), 0, s, a); break;
-        case MODE_JTV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JTV>), dim3(grid), dim3(T), 0, s, a); break;
-        default: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED>), dim3(grid), dim3(T), 0, s, a); break;
+        case MODE_JV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JV, NT>), dim3(grid), dim3(T), 0, s, a); break;
+        case MODE_JTV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JTV, NT>), dim3(grid), dim3(T), 0, s, a); break;
+        default: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, NT>), dim3(grid), dim3(T), 0, s, a); break;
     }
 }
 
@@ -154,6 +156,7 @@ void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipS
         case 6: launch_rs_mode<512, 4, 4>(mode, a, grid, s); break;
         case 7: launch_rs_mode<256, 8, 2>(mode, a, grid, s); break;
         case 8: launch_rs_mode<1024, 2, 4>(mode, a, grid, s); break;
+        case 10: launch_rs_mode<256, 8, 4, 0>(mode, a, grid, s); break;
         default: launch_rs_mode<512, 4, 2>(mode, a, grid, s); break;
     }
 }

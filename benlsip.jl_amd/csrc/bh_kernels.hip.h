@@ -18,6 +18,8 @@
 
 namespace bh {
 
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------------------------------
 // wave64 reductions: DPP inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across
 // rows (gfx950).  Butterfly form: every lane ends with the same bits (a+b == b+a).
@@ -125,7 +127,8 @@ struct RowStreamArgs {
     int reverse;            // sweep the row groups last-to-first (ping-pong order keeps the tail of J in the Infinity Cache)
 };
 
-template <int T, int CPT, int R, int MODE>
+// NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
+template <int T, int CPT, int R, int MODE, int NT = 1>
 __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     if (a.state != nullptr && a.state->done) return;
     constexpr int NW = T / 64;
@@ -163,7 +166,14 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 dst[r][k] = make_double2(0.0, 0.0);
-                if (rv && act[k]) dst[r][k] = rp[tid + k * T];
+                if (rv && act[k]) {
+                    if (NT) {
+                        const dvec2 t = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rp + tid + k * T));
+                        dst[r][k] = make_double2(t.x, t.y);
+                    } else {
+                        dst[r][k] = rp[tid + k * T];
+                    }
+                }
             }
         }
     };

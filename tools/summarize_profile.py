@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 output of tools/profile_round.sh) into profiles/<tag>_*.
+FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts exactly half of the bytes of a 16-B/lane streaming read
+(/opt/skills/guides/MI355X_MICROARCH.md §HBM), so HBM read bytes = 2 * FETCH_SIZE * 1024."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+    line = os.path.join(src, "bench_line_under_trace.json")
+    if os.path.exists(line):
+        shutil.copy(line, os.path.join(dst, tag + "_bench_line_under_trace.json"))
+    pmc = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+        if not files:
+            continue
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(files[0])):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for name, vals in acc.items():
+            pmc.setdefault(name, {})[counter + "_KiB_avg"] = sum(vals) / len(vals)
+            pmc[name][counter + "_dispatches"] = len(vals)
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) + --kernel-trace, bench.py --steps 5",
+           "correction": "HBM bytes per launch = 2*FETCH_SIZE*1024 (gfx950 half-count of 16-B/lane reads) + WRITE_SIZE*1024",
+           "kernels": {}}
+    for name, c in pmc.items():
+        f, w = c.get("FETCH_SIZE_KiB_avg"), c.get("WRITE_SIZE_KiB_avg")
+        entry = dict(c)
+        if f is not None and w is not None:
+            entry["hbm_bytes_per_launch"] = 2.0 * f * 1024.0 + w * 1024.0
+        out["kernels"][name] = entry
+    json.dump(out, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
+    for name, e in out["kernels"].items():
+        if "hbm_bytes_per_launch" in e:
+            print("%-80s %.0f bytes/launch" % (name[:80], e["hbm_bytes_per_launch"]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
