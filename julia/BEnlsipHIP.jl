@@ -1,0 +1,122 @@
+# BEnlsipHIP.jl — glue that routes BEnlsip.jl's trust-region subproblem hot path to the MI355X library
+# (include/benlsip_hip.h) WITHOUT editing the package: it only adds more specific Float64 methods next to the
+# parametric ones of src/basic_tralcnlss.jl and src/polyhedral_constraints.jl, so dispatch prefers them.
+#
+#   using BEnlsip; include("julia/BEnlsipHIP.jl"); using .BEnlsipHIP
+#   BEnlsipHIP.init()                       # once per process (one process per GPU)
+#   x, y = tralcnllss(x0, r, jac_r, c, jac_c, A, b, x_l, x_u)   # unchanged outer iteration
+#
+# STATUS: written against the reference at /root/reference and syntax-reviewed only.  No Julia toolchain exists in
+# the build image or on the GPU box, so this file has never been executed there; the executable stand-in is the
+# Python mirror benlsip.jl_amd/operators.py driving the same C ABI (tests/test_parity_gpu.py).
+module BEnlsipHIP
+
+using BEnlsip, LinearAlgebra
+
+const libbh = get(ENV, "BENLSIP_HIP_LIB", "libbenlsip_hip.so")
+
+function check(rc::Int32, what::AbstractString)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:bh_strerror, libbh), Cstring, (Int32,), rc))
+    det = unsafe_string(ccall((:bh_last_error_detail, libbh), Cstring, ()))
+    error("$what: $msg ($rc): $det")      # reference conventions replaced: AssertionError / PosDefException
+end
+
+"""Select the GPU (default: LOCAL_RANK or 0).  `flags = 1` records hipEvents around H*p launches (bh_stats)."""
+init(device::Integer = parse(Int, get(ENV, "LOCAL_RANK", "0")); flags::Integer = 0) =
+    check(ccall((:bh_init, libbh), Int32, (Int32, Int32), device, flags), "bh_init")
+
+# ---- AlHessian (src/basic_tralcnlss.jl:6-10): device image cached per OBJECT -----------------------------------------
+# A new AlHessian is constructed at every J change (:46, :84); keying on the object (not on the J array, which a user
+# jac_res may reuse) makes that the upload point.
+mutable struct HessHandle
+    ptr::Ptr{Cvoid}
+end
+const HESS = WeakKeyDict{BEnlsip.AlHessian{Float64},HessHandle}()
+
+function handle(H::BEnlsip.AlHessian{Float64})
+    h = get!(HESS, H) do
+        d, n = size(H.J)
+        q = size(H.C, 1)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bh_hess_create, libbh), Int32,
+                    (Ref{Ptr{Cvoid}}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Float64),
+                    ref, H.J, d, n, max(stride(H.J, 2), 1), H.C, q, max(stride(H.C, 2), 1), H.mu), "bh_hess_create")
+        hh = HessHandle(ref[])
+        finalizer(x -> ccall((:bh_hess_destroy, libbh), Int32, (Ptr{Cvoid},), x.ptr), hh)
+        hh
+    end
+    check(ccall((:bh_hess_set_mu, libbh), Int32, (Ptr{Cvoid}, Float64), h.ptr, H.mu), "bh_hess_set_mu")
+    return h.ptr
+end
+
+# Base.:*(H, v) — src/basic_tralcnlss.jl:102-106
+function Base.:*(H::BEnlsip.AlHessian{Float64}, v::Vector{Float64})
+    out = Vector{Float64}(undef, size(H.J, 2))
+    check(ccall((:bh_hmul, libbh), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), handle(H), v, out), "bh_hmul")
+    return out
+end
+
+# vthv(H, v) — src/basic_tralcnlss.jl:92-96
+function BEnlsip.vthv(H::BEnlsip.AlHessian{Float64}, v::Vector{Float64})
+    out = Ref{Float64}(0.0)
+    check(ccall((:bh_vthv, libbh), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ref{Float64}), handle(H), v, out), "bh_vthv")
+    return out[]
+end
+
+# ---- MixedConstraints (src/polyhedral_constraints.jl:1-7) -----------------------------------------------------------
+mutable struct ProjHandle
+    ptr::Ptr{Cvoid}
+end
+const PROJ = WeakKeyDict{BEnlsip.MixedConstraints{Float64},ProjHandle}()
+
+function handle(lincons::BEnlsip.MixedConstraints{Float64})
+    h = get!(PROJ, lincons) do
+        mA, n = size(lincons.lineq)
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bh_proj_create, libbh), Int32, (Ref{Ptr{Cvoid}}, Ptr{Float64}, Int64, Int64, Int64),
+                    ref, lincons.lineq, mA, n, max(stride(lincons.lineq, 2), 1)), "bh_proj_create")
+        hh = ProjHandle(ref[])
+        finalizer(x -> ccall((:bh_proj_destroy, libbh), Int32, (Ptr{Cvoid},), x.ptr), hh)
+        hh
+    end
+    # fixvars / chol are mutated between CG calls (active_bounds!, add_active!, update_chol! — :62-68, :203-261):
+    # re-push on every use (n/8 + 8*mpp^2 bytes).  Only the lower triangle is read by the library; the factor built by
+    # cholesky_aug_aat has uplo == 'L' (factors = L), the initial cholesky(A*A') has uplo == 'U' (SURVEY.md §0.3-15).
+    mA, n = size(lincons.lineq)
+    mpp = mA + count(lincons.fixvars)
+    L = lincons.chol.uplo == 'L' ? lincons.chol.factors : Matrix(lincons.chol.L)
+    check(ccall((:bh_proj_set_active, libbh), Int32,
+                (Ptr{Cvoid}, Ptr{UInt64}, Int64, Ptr{Float64}, Int64, Int64),
+                h.ptr, lincons.fixvars.chunks, n, L, mpp, max(stride(L, 2), 1)), "bh_proj_set_active")
+    return h.ptr
+end
+
+# projection!(lincons, r, v) — src/polyhedral_constraints.jl:158-170  (projection(lincons, r) :150-155 calls it)
+function BEnlsip.projection!(lincons::BEnlsip.MixedConstraints{Float64}, r::Vector{Float64}, v::Vector{Float64})
+    check(ccall((:bh_project, libbh), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), handle(lincons), r, v), "bh_project")
+    return
+end
+
+# ---- projected_cg (src/basic_tralcnlss.jl:690-764) ------------------------------------------------------------------
+function BEnlsip.projected_cg(g_minor::Vector{Float64}, H::BEnlsip.AlHessian{Float64}, w_l::Vector{Float64},
+                              w_u::Vector{Float64}, lincons::BEnlsip.MixedConstraints{Float64}, kappa2::Float64;
+                              atol::Float64 = sqrt(eps(Float64)))
+    n = length(g_minor)
+    w = Vector{Float64}(undef, n)
+    status = Ref{Int32}(-1); iters = Ref{Int32}(0); nh = Ref{Int32}(0)
+    check(ccall((:bh_pcg, libbh), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Float64,
+                 Ptr{Float64}, Ref{Int32}, Ref{Int32}, Ptr{Float64}, Int64, Ref{Int32}),
+                handle(H), handle(lincons), g_minor, w_l, w_u, kappa2, atol, 1e-10,
+                w, status, iters, C_NULL, 0, nh), "bh_pcg")
+    # 0..3 = CG_status (:12); 4 = the reference's `nothing` (iterations exhausted or max_iter == 0, :753-761)
+    return w, (status[] == 4 ? nothing : BEnlsip.CG_status(status[]))
+end
+
+# ---- multi-GPU: one Julia process per GPU (e.g. MPI.jl / Distributed); rows of J and of r are sharded by the caller ----
+unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bh_comm_unique_id, libbh), Int32, (Ptr{UInt8},), id), "bh_comm_unique_id"); id)
+comm_init(rank::Integer, nranks::Integer, id::Vector{UInt8}) =
+    check(ccall((:bh_comm_init, libbh), Int32, (Int32, Int32, Ptr{UInt8}), rank, nranks, id), "bh_comm_init")
+
+end # module
