@@ -121,14 +121,14 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import benlsip_jl_amd as bh
     bh.init(local_rank, flags=bh._lib.BH_FLAG_PROFILE)
-    if world > 1:
+    if dist is not None:
         bh.init_distributed(rank, world, bh.torch_broadcast_bytes(torch.device("cuda", local_rank)))
 
     def barrier():

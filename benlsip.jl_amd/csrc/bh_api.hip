@@ -44,6 +44,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
     int64_t opt_pingpong = 0;        // alternate the sweep direction of J between consecutive H*p products (A/B: +1 % without nt loads, -0.2 % with)
     // RCCL
     void* rccl_lib = nullptr;
@@ -202,8 +203,12 @@ struct bh_proj {
     bool active_set = false;
     int* fixrank = nullptr;        // ldA ints
     int* fixidx = nullptr;         // n ints
-    double* L = nullptr;           // mpp x mpp
+    double* L = nullptr;           // mpp x mpp: the caller's augmented factor (reference form)
     int64_t L_cap = 0;
+    bool have_L = false;
+    double* Lr = nullptr;          // mA x mA: chol(A_free A_free'), built on the device (reduced form)
+    int* info = nullptr;           // device flag of chol_lower_kernel
+    bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
     double* tw = nullptr;          // n + 16
     double* rpad = nullptr;        // ldA
     double* vtmp = nullptr;        // ldA
@@ -238,7 +243,7 @@ int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
 }
 
 int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H) {
-    if (g_ctx.nranks <= 1 || g_ctx.comm == nullptr) return BH_OK;
+    if (g_ctx.comm == nullptr) return BH_OK;
     BH_NCCL(g_ctx.p_ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_ctx.comm, g_ctx.stream));
     if (H) H->stats.n_allreduce += 1;
     return BH_OK;
@@ -364,13 +369,18 @@ int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_dev
 }
 
 // ---- projection -------------------------------------------------------------------------
-ProjArgs proj_args(bh_proj* P, const CgState* st) {
+ProjArgs proj_args(bh_proj* P, const CgState* st, bool reduced) {
     ProjArgs a{};
-    a.A = P->Ad; a.ldA = P->ldA; a.mA = (int)P->mA; a.n = (int)P->n; a.nfix = P->nfix; a.mpp = P->mpp;
+    a.A = P->Ad; a.ldA = P->ldA; a.mA = (int)P->mA; a.n = (int)P->n; a.nfix = P->nfix;
     a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
-    a.fixidx = P->fixidx; a.L = P->L; a.tw = P->tw; a.state = st;
+    a.fixidx = P->fixidx; a.tw = P->tw; a.state = st;
+    a.reduced = reduced ? 1 : 0;
+    a.L = reduced ? P->Lr : P->L;
+    a.mpp = reduced ? (int)P->mA : (int)P->mA + P->nfix;
     return a;
 }
+
+size_t trsv_lds_bytes(int m) { return ((size_t)((m + 1) & ~1) + 64 * 65) * sizeof(double); }
 
 // v_out = P(r_pad): r_pad is a zero-padded ldA-length device vector, v_out has >= n entries.
 int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgState* st) {
@@ -382,13 +392,12 @@ int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgS
         BH_HIP(hipGetLastError());
         return BH_OK;
     }
-    ProjArgs a = proj_args(P, st);
-    const int grid1 = (a.mA + 3) / 4 + (a.nfix + 255) / 256;
+    ProjArgs a = proj_args(P, st, P->reduced);
+    const int grid1 = a.mA + (a.reduced ? 0 : (a.nfix + 255) / 256);
     hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, r_pad);
-    const size_t lds = ((size_t)((a.mpp + 1) & ~1) + 64 * 65) * sizeof(double);
-    hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), lds, g_ctx.stream, a);
+    hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), trsv_lds_bytes(a.mpp), g_ctx.stream, a);
     const int nch = (n + 1) / 2;
-    hipLaunchKernelGGL((proj_left_mul_tr_kernel<true>), dim3((nch + 255) / 256), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
+    hipLaunchKernelGGL((proj_left_mul_tr_kernel<true>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
     BH_HIP(hipGetLastError());
     return BH_OK;
 }
@@ -445,6 +454,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = atoll(s);
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(1, atoll(s));
     if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
+    if (const char* s = getenv("BH_PROJ_FORM")) g_ctx.opt_proj_form = atoll(s) ? 1 : 0;
     g_ctx.init = true;
     return BH_OK;
 }
@@ -495,6 +505,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "blocks_per_cu")) { g_ctx.opt_blocks_per_cu = value; return BH_OK; }
     if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(1, value); return BH_OK; }
     if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }
@@ -535,7 +546,10 @@ int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id_in) {
     BH_REQUIRE_INIT();
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(BH_ERR_INVALID_ARG, "bad rank/nranks");
     if (g_ctx.comm) return fail(BH_ERR_INVALID_ARG, "communicator already initialised");
-    if (nranks == 1) { g_ctx.rank = 0; g_ctx.nranks = 1; return BH_OK; }
+    // nranks == 1 needs no communicator; BH_FORCE_COMM=1 creates a 1-rank RCCL communicator anyway so that the whole
+    // RCCL path (dlopen, ncclCommInitRank, ncclAllReduce on the library stream) can be exercised on a one-GPU box.
+    const char* force = getenv("BH_FORCE_COMM");
+    if (nranks == 1 && !(force && atoi(force) != 0)) { g_ctx.rank = 0; g_ctx.nranks = 1; return BH_OK; }
     if (!id_in) return fail(BH_ERR_INVALID_ARG, "NULL unique id");
     BH_TRY(load_rccl());
     ncclUniqueId id;
@@ -725,27 +739,51 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     const int nfix = (int)idx.size();
     const int64_t want = P->mA + nfix;
     if (want > n) return fail(BH_ERR_PRECONDITION, "mpp = mA + count(fixvars) > n (src/polyhedral_constraints.jl:43,128)");
+    const bool reduced = (P->mA > 0) && (g_ctx.opt_proj_form != 0);
     if (P->mA > 0) {
-        if (!L) return fail(BH_ERR_INVALID_ARG, "L is required when mA > 0");
-        if (mpp != want) return fail(BH_ERR_SHAPE, "mpp != mA + count(fixvars)");
-        if (ldL < mpp) return fail(BH_ERR_INVALID_ARG, "ldL < mpp");
-        if (mpp * mpp > P->L_cap) {
-            dev_free(P->L); P->L = nullptr; P->L_cap = 0;
-            BH_TRY(dev_alloc(&P->L, mpp * mpp));
-            P->L_cap = mpp * mpp;
+        if (!L && !reduced) return fail(BH_ERR_INVALID_ARG, "L is required when mA > 0 (augmented form)");
+        P->have_L = false;
+        if (L) {
+            if (mpp != want) return fail(BH_ERR_SHAPE, "mpp != mA + count(fixvars)");
+            if (ldL < mpp) return fail(BH_ERR_INVALID_ARG, "ldL < mpp");
+            if (!reduced) {
+                if (mpp * mpp > P->L_cap) {
+                    dev_free(P->L); P->L = nullptr; P->L_cap = 0;
+                    BH_TRY(dev_alloc(&P->L, mpp * mpp));
+                    P->L_cap = mpp * mpp;
+                }
+                BH_HIP(hipMemcpy2DAsync(P->L, (size_t)mpp * sizeof(double), L, (size_t)ldL * sizeof(double), (size_t)mpp * sizeof(double),
+                                        (size_t)mpp, hipMemcpyHostToDevice, g_ctx.stream));
+                P->have_L = true;
+            }
         }
-        BH_HIP(hipMemcpy2DAsync(P->L, (size_t)mpp * sizeof(double), L, (size_t)ldL * sizeof(double), (size_t)mpp * sizeof(double),
-                                (size_t)mpp, hipMemcpyHostToDevice, g_ctx.stream));
-        const size_t lds = ((size_t)((mpp + 1) & ~1) + 64 * 65) * sizeof(double);
-        if (lds > 160 * 1024) return fail(BH_ERR_UNSUPPORTED, "mpp too large for the single-workgroup triangular solve");
+        const size_t lds = trsv_lds_bytes(reduced ? (int)P->mA : (int)want);
+        if (lds > 160 * 1024) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
         BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     } else if (mpp != want && L != nullptr) {
         return fail(BH_ERR_SHAPE, "mpp != count(fixvars) for mA == 0");
     }
     BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
     if (nfix > 0) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), (size_t)nfix * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+    P->nfix = nfix; P->mpp = (int)want; P->reduced = reduced;
+    int info_host = 0;
+    if (reduced) {
+        // reduced form: factor A_free A_free' (mA x mA) on the device; bound changes need no host factor
+        const int mA = (int)P->mA;
+        if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, (int64_t)mA * mA));
+        if (!P->info) BH_TRY(dev_alloc(&P->info, 1));
+        const int64_t pairs = (int64_t)mA * (mA + 1) / 2;
+        hipLaunchKernelGGL(gram_free_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
+                           nfix > 0 ? P->fixrank : (const int*)nullptr, P->Lr);
+        hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->Lr, mA, P->info);
+        BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+    }
     BH_HIP(hipStreamSynchronize(g_ctx.stream));   // host vectors go out of scope
-    P->nfix = nfix; P->mpp = (int)want; P->active_set = true;
+    if (info_host != 0) {
+        P->active_set = false;
+        return fail(BH_ERR_PRECONDITION, "A_free*A_free' is not positive definite (PosDefException in the reference's cholesky)");
+    }
+    P->active_set = true;
     return BH_OK;
 }
 
@@ -753,6 +791,7 @@ int32_t bh_proj_destroy(bh_proj* P) {
     if (!P) return BH_OK;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
+    dev_free(P->Lr); dev_free(P->info);
     delete P;
     return BH_OK;
 }
@@ -782,8 +821,8 @@ int32_t bh_left_mul(bh_proj* P, const double* x, double* out_mpp) {
     BH_REQUIRE_INIT();
     if (!P || !x || !out_mpp) return fail(BH_ERR_INVALID_ARG, "NULL argument");
     BH_TRY(stage_vec(P->rpad, x, P->n, false));
-    ProjArgs a = proj_args(P, nullptr);
-    const int grid1 = (a.mA + 3) / 4 + (a.nfix + 255) / 256;
+    ProjArgs a = proj_args(P, nullptr, false);
+    const int grid1 = a.mA + (a.nfix + 255) / 256;
     if (grid1 > 0) hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, P->rpad);
     BH_HIP(hipGetLastError());
     BH_TRY(fetch_vec(out_mpp, P->tw, P->mA + P->nfix, false));
@@ -795,9 +834,9 @@ int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
     BH_REQUIRE_INIT();
     if (!P || !y || !out_n) return fail(BH_ERR_INVALID_ARG, "NULL argument");
     BH_TRY(stage_vec(P->tw, y, P->mA + P->nfix, false));
-    ProjArgs a = proj_args(P, nullptr);
+    ProjArgs a = proj_args(P, nullptr, false);
     const int nch = ((int)P->n + 1) / 2;
-    hipLaunchKernelGGL((proj_left_mul_tr_kernel<false>), dim3((nch + 255) / 256), dim3(256), 0, g_ctx.stream, a,
+    hipLaunchKernelGGL((proj_left_mul_tr_kernel<false>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a,
                        (const double*)nullptr, P->vtmp);
     BH_HIP(hipGetLastError());
     BH_TRY(fetch_vec(out_n, P->vtmp, P->n, false));

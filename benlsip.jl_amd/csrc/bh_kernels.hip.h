@@ -719,12 +719,13 @@ __global__ __launch_bounds__(CG_T) void f2b_kernel(const double* p, const double
 struct ProjArgs {
     const double* A;        // row-major mA x ldA image of lineq (NULL when mA == 0)
     int64_t ldA;
-    int mA, n, nfix, mpp;
+    int mA, n, nfix, mpp;   // mpp = order of the factor in use (mA + nfix augmented, mA reduced)
     const int* fixrank;     // n   (-1 free)
     const int* fixidx;      // nfix
     const double* L;        // mpp x mpp column-major, lower triangle valid
     double* tw;             // mpp workspace
     const CgState* state;   // NULL, or skip unless (!done && need_proj)
+    int reduced;            // 1: reduced form  v_free = r_free - A_free'(A_free A_free')^{-1} A_free r_free, v_fix = 0
 };
 
 __device__ __forceinline__ bool proj_skip(const CgState* st) { return st != nullptr && (st->done || !st->need_proj); }
@@ -737,60 +738,144 @@ __global__ __launch_bounds__(256) void proj_mask_kernel(const double* __restrict
         v[i] = (fixrank != nullptr && fixrank[i] >= 0) ? 0.0 : r[i];
 }
 
-// left_mul: tw[0:mA] = A x (one wave per row), tw[mA+k] = x[fixidx[k]] (:86-98).
-// grid = ceil(mA/4) + ceil(nfix/256) blocks of 256.
+// left_mul: tw[0:mA] = A x (one workgroup per row: 4 waves share the row, fixed-order combine), and in the augmented
+// form tw[mA+k] = x[fixidx[k]] (:86-98).  Reduced form: the fixed components of x are masked out (A_free x_free).
+// grid = mA + ceil(nfix/256) blocks of 256 (gather blocks only in the augmented form).
 __global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const double* __restrict__ x) {
     if (proj_skip(a.state)) return;
-    const int row_blocks = (a.mA + 3) / 4;
-    if ((int)blockIdx.x < row_blocks) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int row = blockIdx.x * 4 + wave;
-        if (row >= a.mA) return;
+    __shared__ double scratch[4];
+    if ((int)blockIdx.x < a.mA) {
+        const int row = blockIdx.x;
         const double2* rp = reinterpret_cast<const double2*>(a.A + (int64_t)row * a.ldA);
         const double2* x2 = reinterpret_cast<const double2*>(x);
+        const int2* f2 = reinterpret_cast<const int2*>(a.fixrank);
         const int nch = (int)(a.ldA >> 1);
-        double acc = 0.0;
-        for (int c = lane; c < nch; c += 64) {
-            const double2 av = rp[c], xv = x2[c];
-            acc = fma(av.x, xv.x, acc);
-            acc = fma(av.y, xv.y, acc);
+        const bool mask = a.reduced && a.fixrank != nullptr;
+        double acc[1] = {0.0};
+        for (int c = threadIdx.x; c < nch; c += 256) {
+            const double2 av = rp[c];
+            double2 xv = x2[c];
+            if (mask) {
+                const int2 f = f2[c];
+                if (f.x >= 0) xv.x = 0.0;
+                if (f.y >= 0) xv.y = 0.0;
+            }
+            acc[0] = fma(av.x, xv.x, acc[0]);
+            acc[0] = fma(av.y, xv.y, acc[0]);
         }
-        acc = wave_sum(acc);
-        if (lane == 0) a.tw[row] = acc;
-    } else {
-        const int k = ((int)blockIdx.x - row_blocks) * 256 + threadIdx.x;
+        block_reduce<256, 1>(acc, scratch, OpSum(), 0.0);
+        if (threadIdx.x == 0) a.tw[row] = acc[0];
+    } else if (!a.reduced) {
+        const int k = ((int)blockIdx.x - a.mA) * 256 + threadIdx.x;
         if (k < a.nfix) a.tw[a.mA + k] = x[a.fixidx[k]];
     }
 }
 
 // out = r - left_mul_tr(tw)   (:72-84, :116, :134);  with SUBTRACT=false: out = left_mul_tr(tw).
+// Block = 64 chunks x 4 row groups (rows i = rg, rg+4, ...), combined through LDS in fixed order; grid = ceil(nch/64).
 template <bool SUBTRACT>
 __global__ __launch_bounds__(256) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
     if (proj_skip(a.state)) return;
+    __shared__ double2 sm[4][64];
     const int nch = (a.n + 1) >> 1;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= nch) return;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double2 acc = make_double2(0.0, 0.0);
-    const double2* A2 = reinterpret_cast<const double2*>(a.A);
-    const int64_t ld2 = a.ldA >> 1;
-    for (int i = 0; i < a.mA; ++i) {
-        const double wi = a.tw[i];
-        const double2 av = A2[(int64_t)i * ld2 + c];
-        acc.x = fma(wi, av.x, acc.x);
-        acc.y = fma(wi, av.y, acc.y);
+    if (c < nch) {
+        const double2* A2 = reinterpret_cast<const double2*>(a.A);
+        const int64_t ld2 = a.ldA >> 1;
+        for (int i = rg; i < a.mA; i += 4) {
+            const double wi = a.tw[i];
+            const double2 av = A2[(int64_t)i * ld2 + c];
+            acc.x = fma(wi, av.x, acc.x);
+            acc.y = fma(wi, av.y, acc.y);
+        }
     }
+    sm[rg][cl] = acc;
+    __syncthreads();
+    if (rg != 0 || c >= nch) return;
+    acc.x = (sm[0][cl].x + sm[1][cl].x) + (sm[2][cl].x + sm[3][cl].x);
+    acc.y = (sm[0][cl].y + sm[1][cl].y) + (sm[2][cl].y + sm[3][cl].y);
     const int j0 = 2 * c, j1 = 2 * c + 1;
-    if (a.fixrank != nullptr) {
-        const int k0 = a.fixrank[j0];
-        if (k0 >= 0) acc.x += a.tw[a.mA + k0];
-        if (j1 < a.n) { const int k1 = a.fixrank[j1]; if (k1 >= 0) acc.y += a.tw[a.mA + k1]; }
+    int k0 = -1, k1 = -1;
+    if (a.fixrank != nullptr) { k0 = a.fixrank[j0]; if (j1 < a.n) k1 = a.fixrank[j1]; }
+    if (a.reduced) {
+        // fixed components of the projection are exactly zero
+        if (SUBTRACT) {
+            out[j0] = (k0 >= 0) ? 0.0 : r[j0] - acc.x;
+            if (j1 < a.n) out[j1] = (k1 >= 0) ? 0.0 : r[j1] - acc.y;
+        } else {
+            out[j0] = (k0 >= 0) ? 0.0 : acc.x;
+            if (j1 < a.n) out[j1] = (k1 >= 0) ? 0.0 : acc.y;
+        }
+        return;
     }
+    if (k0 >= 0) acc.x += a.tw[a.mA + k0];
+    if (k1 >= 0) acc.y += a.tw[a.mA + k1];
     if (SUBTRACT) {
         out[j0] = r[j0] - acc.x;
         if (j1 < a.n) out[j1] = r[j1] - acc.y;
     } else {
         out[j0] = acc.x;
         if (j1 < a.n) out[j1] = acc.y;
+    }
+}
+
+// Reduced-form factor, built on the device whenever the active set changes (bh_proj_set_active):
+//   M = A_free A_free'  (lower triangle, column-major mA x mA): one wave per entry (i >= k).
+__global__ __launch_bounds__(256) void gram_free_kernel(const double* __restrict__ A, int64_t ldA, int mA, const int* __restrict__ fixrank,
+                                                        double* __restrict__ M) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // packed lower-triangular index
+    const int64_t total = (int64_t)mA * (mA + 1) / 2;
+    if (e >= total) return;
+    // e = i*(i+1)/2 + k, 0 <= k <= i
+    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(i + 1) * (i + 2) / 2 <= e) ++i;
+    while ((int64_t)i * (i + 1) / 2 > e) --i;
+    const int k = (int)(e - (int64_t)i * (i + 1) / 2);
+    const double2* ri = reinterpret_cast<const double2*>(A + (int64_t)i * ldA);
+    const double2* rk = reinterpret_cast<const double2*>(A + (int64_t)k * ldA);
+    const int2* f2 = reinterpret_cast<const int2*>(fixrank);
+    const int nch = (int)(ldA >> 1);
+    double acc = 0.0;
+    for (int c = lane; c < nch; c += 64) {
+        const double2 x = ri[c], y = rk[c];
+        int2 f = make_int2(-1, -1);
+        if (fixrank != nullptr) f = f2[c];
+        if (f.x < 0) acc = fma(x.x, y.x, acc);
+        if (f.y < 0) acc = fma(x.y, y.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) M[i + (int64_t)k * mA] = acc;
+}
+
+// In-place lower Cholesky of the mA x mA matrix M (column-major, lower triangle), single workgroup, right-looking.
+// info[0] = 0 on success, else 1 + index of the first non-positive pivot (the reference's PosDefException).
+__global__ __launch_bounds__(CG_T) void chol_lower_kernel(double* __restrict__ M, int m, int* info) {
+    __shared__ double s_piv;
+    const int tid = threadIdx.x;
+    if (tid == 0) info[0] = 0;
+    for (int j = 0; j < m; ++j) {
+        if (tid == 0) {
+            const double d = M[j + (int64_t)j * m];
+            if (!(d > 0.0) && info[0] == 0) info[0] = j + 1;
+            s_piv = sqrt(d);
+        }
+        __syncthreads();
+        const double piv = s_piv;
+        for (int i = j + tid; i < m; i += CG_T) M[i + (int64_t)j * m] = (i == j) ? piv : M[i + (int64_t)j * m] / piv;
+        __syncthreads();
+        // trailing update of the lower triangle: M[i][k] -= L[i][j]*L[k][j], j < k <= i
+        const int rem = m - j - 1;
+        for (int64_t e = tid; e < (int64_t)rem * rem; e += CG_T) {
+            const int kk = (int)(e / rem), ii = (int)(e - (int64_t)kk * rem);
+            if (ii >= kk) {
+                const int i = j + 1 + ii, k = j + 1 + kk;
+                M[i + (int64_t)k * m] = fma(-M[i + (int64_t)j * m], M[k + (int64_t)j * m], M[i + (int64_t)k * m]);
+            }
+        }
+        __syncthreads();
     }
 }
 

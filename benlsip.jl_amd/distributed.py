@@ -28,8 +28,9 @@ def init_distributed(rank, nranks, broadcast_bytes):
     ``broadcast_bytes(buf: bytes | None) -> bytes`` must return rank 0's buffer on every rank (e.g. built on
     ``torch.distributed.broadcast`` or an MPI bcast).
     """
+    import os
     lib = _lib.lib()
-    if nranks == 1:
+    if nranks == 1 and os.environ.get("BH_FORCE_COMM", "0") in ("", "0"):
         check(lib.bh_comm_init(0, 1, None), "bh_comm_init")
         return
     buf = None

@@ -245,9 +245,9 @@ class MixedConstraints:
         mpp = self.mA + self.nb_fix()
         L = None
         ldL = max(mpp, 1)
-        if self.mA > 0:
-            if self._chol is None:
-                raise ValueError("MixedConstraints: a Cholesky factor is required when lineq has rows")
+        if self.mA > 0 and self._chol is not None:
+            # the reference's augmented factor; only needed by the library's proj_form = 0 (reference form) —
+            # the default reduced form factors A_free A_free' on the device and ignores it
             L = np.asfortranarray(self._chol)
             if L.shape != (mpp, mpp):
                 raise ValueError("chol factor is %r, expected (%d, %d) = mA + count(fixvars)" % (L.shape, mpp, mpp))

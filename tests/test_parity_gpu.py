@@ -104,11 +104,21 @@ def test_hs48_projection_known_answer(bh):
     assert np.array_equal(v, proj)
 
 
+@pytest.fixture(params=[1, 0], ids=["reduced_form", "augmented_form"])
+def proj_form(request, bh):
+    """Both projection forms of the library: 1 = reduced mA x mA factor built on the device (default), 0 = the
+    reference's augmented mpp x mpp factor handed over by the caller."""
+    bh._lib.lib().bh_set_option(b"proj_form", request.param)
+    yield request.param
+    bh._lib.lib().bh_set_option(b"proj_form", 1)
+
+
 @pytest.mark.parametrize("n,mA,nfix", [(6, 3, 3), (7, 3, 0), (40, 5, 10), (300, 20, 150), (300, 20, 0), (130, 64, 66), (1000, 64, 512),
-                                       (513, 1, 1), (64, 0, 9), (64, 0, 0), (4096, 64, 512)])
-def test_projection_parity(bh, n, mA, nfix):
+                                       (513, 1, 1), (64, 0, 9), (64, 0, 0), (4096, 64, 512), (700, 130, 200)])
+def test_projection_parity(bh, proj_form, n, mA, nfix):
     """projection_nullspace! / projection_subspace! (src/polyhedral_constraints.jl:104-136) incl. garbage in the unread
-    upper triangle of the factor."""
+    upper triangle of the factor.  Tolerance: a normal-equations projector is accurate to
+    ~eps*cond(B B') with B = [A; I_fix]; 1e-11*||r|| floor, 200*eps*cond above it (only (130,64,66), mpp == n, needs it)."""
     rng = np.random.default_rng(n + 7 * mA + nfix)
     A = rng.standard_normal((mA, n))
     L0 = R.chol_lower(A @ A.T)
@@ -119,17 +129,42 @@ def test_projection_parity(bh, n, mA, nfix):
     if L.shape[0] > 1:
         L[np.triu_indices(L.shape[0], 1)] = np.nan        # uninitialised upper triangle must never be read
     cons = bh.MixedConstraints(A, L, fix)
+    B = np.vstack([A, np.eye(n)[fix]])
+    tol = max(1e-11, 200 * np.finfo(float).eps * np.linalg.cond(B @ B.T)) if B.shape[0] else 1e-11
     for _ in range(2):
         r = rng.standard_normal(n)
         v_ref = R.projection(cons_o, r)
         v = bh.projection(cons, r)
-        assert np.linalg.norm(v - v_ref) <= 1e-11 * np.linalg.norm(r), (n, mA, nfix)
+        assert np.linalg.norm(v - v_ref) <= tol * np.linalg.norm(r), (n, mA, nfix, np.linalg.norm(v - v_ref) / np.linalg.norm(r), tol)
         if mA:
-            assert np.linalg.norm(A @ v) <= 1e-10 * np.linalg.norm(A) * np.linalg.norm(r)
-        assert np.all(v[fix] == 0.0) if mA == 0 else np.max(np.abs(v[fix]), initial=0.0) <= 1e-12 * np.linalg.norm(r)
-        # idempotence of an orthogonal projector (loose: at mpp == n the null space is {0} and v is pure rounding noise
-        # of size cond(L)*eps*||r||)
-        assert np.linalg.norm(bh.projection(cons, v) - v) <= 1e-9 * np.linalg.norm(r)
+            assert np.linalg.norm(A @ v) <= 10 * tol * np.linalg.norm(A) * np.linalg.norm(r)
+        if mA == 0 or proj_form == 1:
+            assert np.all(v[fix] == 0.0)
+        else:
+            assert np.max(np.abs(v[fix]), initial=0.0) <= tol * np.linalg.norm(r)
+        # idempotence of an orthogonal projector
+        assert np.linalg.norm(bh.projection(cons, v) - v) <= 100 * tol * np.linalg.norm(r)
+
+
+def test_reduced_form_needs_no_host_factor_and_reports_rank_deficiency(bh):
+    """Default (reduced) form: the caller's factor is optional; a rank-deficient A_free is reported like the reference's
+    PosDefException instead of producing garbage."""
+    bh._lib.lib().bh_set_option(b"proj_form", 1)
+    rng = np.random.default_rng(5)
+    n, mA = 60, 4
+    A = rng.standard_normal((mA, n))
+    fix = np.zeros(n, dtype=bool)
+    fix[:7] = True
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix)
+    cons = bh.MixedConstraints(A, None, fix)                   # no factor handed over
+    r = rng.standard_normal(n)
+    assert relnorm(bh.projection(cons, r), R.projection(cons_o, r)) <= 1e-12
+    A2 = A.copy()
+    A2[3] = 0.0                                                 # rank-deficient: a zero pivot, exactly
+    bad = bh.MixedConstraints(A2, None, fix)
+    with pytest.raises(bh.BenlsipHipError) as e:
+        bh.projection(bad, r)
+    assert e.value.code == -5
 
 
 def test_projection_follows_active_set_changes(bh):
@@ -159,6 +194,14 @@ def test_preconditions_are_reported_not_asserted(bh):
     cons.set_active(np.array([True, False, False, False]), np.eye(2))     # factor of the wrong order
     with pytest.raises(ValueError):
         bh.projection(cons, np.ones(4))
+    bh._lib.lib().bh_set_option(b"proj_form", 0)                          # reference form requires the factor
+    try:
+        cons.set_active(np.array([True, False, False, False]), None)
+        with pytest.raises(bh.BenlsipHipError) as e:
+            bh.projection(cons, np.ones(4))
+        assert e.value.code == -1
+    finally:
+        bh._lib.lib().bh_set_option(b"proj_form", 1)
     H = bh.AlHessian(np.ones((3, 5)), None, 1.0)
     cons4 = bh.MixedConstraints(np.zeros((0, 4)))
     with pytest.raises(bh.BenlsipHipError) as e:
@@ -250,6 +293,25 @@ def test_pcg_random_instances(bh, d, n, q, mA, nfix, seed):
         assert np.linalg.norm(A @ w) <= 1e-9 * np.linalg.norm(A) * np.linalg.norm(w)
     assert np.max(np.abs(w[fix]), initial=0.0) <= 1e-12 * np.linalg.norm(w)
     H.close()
+
+
+def test_pcg_config5_shape_linear_constraints(bh, proj_form):
+    """BASELINE config 5 shape at oracle-sized d: n=1024, mA=16 linear equalities + p=128 active bounds (mpp=144)."""
+    d, n, mA = 2048, 1024, 16
+    J = R.synthetic_J(d, n, seed=1)
+    inst = R.synthetic_box_vectors(d, n, fix_every=8)
+    A = R.splitmix_uniform(4, np.arange(mA * n)).reshape((mA, n), order="F")
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    Ho = R.AlHessian(J, np.zeros((0, n)), 10.0)
+    g = J.T @ inst.r0
+    w_l, w_u = R.build_step_bounds(inst.x, cons_o, 0.1 * np.linalg.norm(g))
+    w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.01)
+    H = bh.AlHessian(J, None, 10.0)
+    cons = bh.MixedConstraints(A, cons_o.chol_L, inst.fixvars)
+    w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.01, full_output=True)
+    assert int(status) == int(s_ref) and info["iters"] == it_ref
+    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.01, w_ref)
+    assert np.linalg.norm(A @ w) <= 1e-10 * np.linalg.norm(A) * np.linalg.norm(w)
 
 
 def test_pcg_config2_synthetic_box(bh):
@@ -368,3 +430,39 @@ def test_sphere_regression_through_c_abi(bh):
     assert np.linalg.norm(xs - P) < 1e-6
     gold = json.load(open(os.path.join(GOLD, "sphere_regression.json")))
     np.testing.assert_allclose(xs, gold["oracle_x"], rtol=1e-6)
+
+
+def test_rccl_path_with_one_rank_communicator():
+    """The RCCL code path (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on the library stream) exercised with a
+    1-rank communicator in a child process (BH_FORCE_COMM=1): results must equal the communicator-free run."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import benlsip_jl_amd as bh
+bh.init(0)
+J = np.random.default_rng(0).standard_normal((700, 300))
+v = np.random.default_rng(1).standard_normal(300)
+H0 = bh.AlHessian(J, None, 1.0)
+a0, g0, s0 = H0 * v, H0.jtv(J @ v), bh.vthv(H0, v)
+if os.environ.get("BH_FORCE_COMM") == "1":
+    bh.init_distributed(0, 1, lambda b: b)
+    r, n = bh._lib.C.c_int32(), bh._lib.C.c_int32()
+    bh._lib.lib().bh_comm_info(bh._lib.C.byref(r), bh._lib.C.byref(n))
+    assert (r.value, n.value) == (0, 1)
+H = bh.AlHessian(J, None, 1.0)
+a, g, s = H * v, H.jtv(J @ v), bh.vthv(H, v)
+assert np.array_equal(a, a0) and np.array_equal(g, g0) and s == s0
+cons = bh.MixedConstraints(np.zeros((0, 300)))
+w, st, info = bh.projected_cg(g, H, np.full(300, -np.inf), np.full(300, np.inf), cons, 0.1, full_output=True)
+print("OK", H.stats()["n_allreduce"], info["n_hmul"])
+bh._lib.lib().bh_comm_destroy()
+""" % root
+    env = dict(os.environ, BH_FORCE_COMM="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    tok = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("OK")][-1].split()    # RCCL prints a banner first
+    assert tok[0] == "OK" and int(tok[1]) >= 3 + int(tok[2])      # hmul + jtv + vthv + one per H*p of the CG run
