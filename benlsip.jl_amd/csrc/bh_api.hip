@@ -209,6 +209,7 @@ struct bh_proj {
     double* Lr = nullptr;          // mA x mA: chol(A_free A_free'), built on the device (reduced form)
     int* info = nullptr;           // device flag of chol_lower_kernel
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
+    std::vector<uint64_t> last_chunks;   // fixvars of the last successful bh_proj_set_active (reduced form: skip identical pushes)
     double* tw = nullptr;          // n + 16
     double* rpad = nullptr;        // ldA
     double* vtmp = nullptr;        // ldA
@@ -380,6 +381,16 @@ ProjArgs proj_args(bh_proj* P, const CgState* st, bool reduced) {
     return a;
 }
 
+// One pass of the CG loop body: register-resident kernel when the vectors fit (n <= 8192), generic otherwise.
+template <int PHASE>
+void launch_cg_step(const CgArgs& a, hipStream_t s) {
+    const int nch = (a.n + 1) / 2;
+    if (nch <= CG_T) hipLaunchKernelGGL((cg_step_reg_kernel<1, PHASE>), dim3(1), dim3(CG_T), 0, s, a);
+    else if (nch <= 2 * CG_T) hipLaunchKernelGGL((cg_step_reg_kernel<2, PHASE>), dim3(1), dim3(CG_T), 0, s, a);
+    else if (nch <= 4 * CG_T) hipLaunchKernelGGL((cg_step_reg_kernel<4, PHASE>), dim3(1), dim3(CG_T), 0, s, a);
+    else hipLaunchKernelGGL((cg_step_kernel<PHASE>), dim3(1), dim3(CG_T), 0, s, a);
+}
+
 size_t trsv_lds_bytes(int m) { return ((size_t)((m + 1) & ~1) + 64 * 65) * sizeof(double); }
 
 // v_out = P(r_pad): r_pad is a zero-padded ldA-length device vector, v_out has >= n entries.
@@ -395,7 +406,8 @@ int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgS
     ProjArgs a = proj_args(P, st, P->reduced);
     const int grid1 = a.mA + (a.reduced ? 0 : (a.nfix + 255) / 256);
     hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, r_pad);
-    hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), trsv_lds_bytes(a.mpp), g_ctx.stream, a);
+    if (a.reduced && a.mpp <= 64) hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, a);
+    else hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), trsv_lds_bytes(a.mpp), g_ctx.stream, a);
     const int nch = (n + 1) / 2;
     hipLaunchKernelGGL((proj_left_mul_tr_kernel<true>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
     BH_HIP(hipGetLastError());
@@ -738,6 +750,14 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     }
     const int nfix = (int)idx.size();
     const int64_t want = P->mA + nfix;
+    const size_t nwords = (size_t)((n + 63) / 64);
+    {   // The Julia shim re-pushes before every projection; with the reduced form (or no linear rows) the device state
+        // depends on fixvars only, so an identical push is a no-op (no upload, no refactorisation).
+        const bool form_reduced = (P->mA == 0) || (g_ctx.opt_proj_form != 0);
+        if (form_reduced && P->active_set && P->reduced == (P->mA > 0) && fix_chunks && P->last_chunks.size() == nwords &&
+            memcmp(P->last_chunks.data(), fix_chunks, nwords * sizeof(uint64_t)) == 0)
+            return BH_OK;       // whole words compared: stray bits beyond n only ever cause a (harmless) rebuild
+    }
     if (want > n) return fail(BH_ERR_PRECONDITION, "mpp = mA + count(fixvars) > n (src/polyhedral_constraints.jl:43,128)");
     const bool reduced = (P->mA > 0) && (g_ctx.opt_proj_form != 0);
     if (P->mA > 0) {
@@ -770,12 +790,13 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     if (reduced) {
         // reduced form: factor A_free A_free' (mA x mA) on the device; bound changes need no host factor
         const int mA = (int)P->mA;
-        if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, (int64_t)mA * mA));
+        if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, (int64_t)mA * mA + mA));
         if (!P->info) BH_TRY(dev_alloc(&P->info, 1));
         const int64_t pairs = (int64_t)mA * (mA + 1) / 2;
         hipLaunchKernelGGL(gram_free_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
                            nfix > 0 ? P->fixrank : (const int*)nullptr, P->Lr);
-        hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->Lr, mA, P->info);
+        if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, P->Lr, mA, P->info);
+        else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->Lr, mA, P->info);
         BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
     }
     BH_HIP(hipStreamSynchronize(g_ctx.stream));   // host vectors go out of scope
@@ -784,6 +805,12 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
         return fail(BH_ERR_PRECONDITION, "A_free*A_free' is not positive definite (PosDefException in the reference's cholesky)");
     }
     P->active_set = true;
+    if (fix_chunks) {
+        // keep a copy with the bits beyond n cleared (Julia keeps them zero; be defensive)
+        P->last_chunks.assign(fix_chunks, fix_chunks + nwords);
+    } else {
+        P->last_chunks.assign(nwords, 0ull);
+    }
     return BH_OK;
 }
 
@@ -878,7 +905,7 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     CgArgs a{};
     a.st = c.d_state; a.w = wp; a.r = c.r; a.v = c.v; a.p = c.p; a.Hp = c.Hp; a.g = gp; a.wl = wlp; a.wu = wup;
     a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
-    a.n = (int)n; a.max_iter = max_iter; a.kappa2 = kappa2; a.atol_neg = atol_negcurv; a.atol_f2b = atol_f2b;
+    a.n = (int)n; a.n_pad = (int)n_pad; a.w_in_ws = in_place ? 0 : 1; a.max_iter = max_iter; a.kappa2 = kappa2; a.atol_neg = atol_negcurv; a.atol_f2b = atol_f2b;
     a.trace = trace_cap > 0 ? c.d_trace : nullptr; a.trace_cap = (int)std::min<int64_t>(trace_cap, 0x7fffffff);
 
     const bool box = (P->mA == 0);
@@ -894,15 +921,11 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     auto launch_iteration = [&](int index) -> int32_t {
         BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, index, g_ctx.opt_pingpong ? (index & 1) : 0));   // :722
         if (box) {
-            const int nch = (int)((n + 1) / 2);
-            if (nch <= CG_T) hipLaunchKernelGGL((cg_step_box_reg_kernel<1>), dim3(1), dim3(CG_T), 0, s, a);
-            else if (nch <= 2 * CG_T) hipLaunchKernelGGL((cg_step_box_reg_kernel<2>), dim3(1), dim3(CG_T), 0, s, a);
-            else if (nch <= 4 * CG_T) hipLaunchKernelGGL((cg_step_box_reg_kernel<4>), dim3(1), dim3(CG_T), 0, s, a);
-            else hipLaunchKernelGGL((cg_step_kernel<0>), dim3(1), dim3(CG_T), 0, s, a);
+            launch_cg_step<0>(a, s);
         } else {
-            hipLaunchKernelGGL((cg_step_kernel<1>), dim3(1), dim3(CG_T), 0, s, a);
+            launch_cg_step<1>(a, s);
             BH_TRY(launch_project(P, c.r, c.v, c.d_state));            // :741
-            hipLaunchKernelGGL((cg_step_kernel<2>), dim3(1), dim3(CG_T), 0, s, a);
+            launch_cg_step<2>(a, s);
         }
         return BH_OK;
     };

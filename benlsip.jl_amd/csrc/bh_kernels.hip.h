@@ -365,6 +365,8 @@ struct CgArgs {
     const double* wl; const double* wu;
     const int* fixrank;     // -1 free, else rank among fixed variables (NULL = nothing fixed)
     int n;
+    int n_pad;              // length of the workspace vectors; init zeroes [n, n_pad) (the workspace is reused across calls)
+    int w_in_ws;            // w points into the padded workspace (else: caller's buffer of exactly n doubles)
     int max_iter;
     double kappa2, atol_neg, atol_f2b;
     double* trace; int trace_cap;
@@ -392,6 +394,10 @@ template <bool BOX>
 __global__ __launch_bounds__(CG_T) void cg_init_kernel(CgArgs a) {
     __shared__ double scratch[2 * (CG_T / 64)];
     double acc[2] = {0.0, 0.0};
+    for (int i = a.n + threadIdx.x; i < a.n_pad; i += CG_T) {     // stale padding from an earlier, larger problem
+        a.r[i] = 0.0; a.v[i] = 0.0; a.p[i] = 0.0;
+        if (a.w_in_ws) a.w[i] = 0.0;
+    }
     for (int i = threadIdx.x; i < a.n; i += CG_T) {
         const double ri = a.g[i];
         a.r[i] = ri;
@@ -562,15 +568,19 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
     }
 }
 
-// Register-resident form of cg_step_kernel<0> (box constraints) for n <= 2*CG_T*CH: every element a thread owns is
-// loaded ONCE with 16-byte loads that are all in flight together, the whole loop body (src/basic_tralcnlss.jl:722-750)
-// runs out of registers with two block reductions, and results are stored once.  One HBM/L2 round trip instead of four.
-template <int CH>
-__global__ __launch_bounds__(CG_T) void cg_step_box_reg_kernel(CgArgs a) {
+// Register-resident forms of cg_step_kernel<PHASE> for n <= 2*CG_T*CH: every element a thread owns is loaded ONCE with
+// 16-byte loads that are all in flight together, the loop body (src/basic_tralcnlss.jl:722-750) runs out of registers
+// with at most two block reductions, and results are stored once.  One HBM/L2 round trip instead of four.
+//   PHASE 0: box constraints, everything fused (projection = mask).
+//   PHASE 1: general constraints, step_a (pHp, gamma, branch, w and r updates; sets need_proj).
+//   PHASE 2: general constraints, step_b after v = P(r) (rtv_next, beta, p, exit test).
+template <int CH, int PHASE>
+__global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
     constexpr int NW = CG_T / 64;
     __shared__ double scratch[2 * NW];
     CgState* st = a.st;
     if (st->done) return;
+    if (PHASE == 2 && !st->need_proj) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const double QNAN = __longlong_as_double(0x7ff8000000000000ll);
@@ -579,74 +589,90 @@ __global__ __launch_bounds__(CG_T) void cg_step_box_reg_kernel(CgArgs a) {
     const int iter0 = st->iter, max_iter = st->max_iter, n_hmul0 = st->n_hmul;
 
     bool act[CH];
-    double2 p[CH], hp[CH], w[CH], wl[CH], wu[CH], r[CH];
+    double2 p[CH], hp[CH], w[CH], wl[CH], wu[CH], r[CH], v[CH];
     int2 fr[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         const int c = tid + k * CG_T;
         act[k] = c < nch;
-        p[k] = hp[k] = w[k] = wl[k] = wu[k] = r[k] = make_double2(0.0, 0.0);
+        p[k] = hp[k] = w[k] = wl[k] = wu[k] = r[k] = v[k] = make_double2(0.0, 0.0);
         fr[k] = make_int2(-1, -1);
         if (act[k]) {
             p[k] = reinterpret_cast<const double2*>(a.p)[c];
-            hp[k] = reinterpret_cast<const double2*>(a.Hp)[c];
-            w[k] = reinterpret_cast<const double2*>(a.w)[c];
-            wl[k] = reinterpret_cast<const double2*>(a.wl)[c];
-            wu[k] = reinterpret_cast<const double2*>(a.wu)[c];
             r[k] = reinterpret_cast<const double2*>(a.r)[c];
-            if (a.fixrank != nullptr) fr[k] = reinterpret_cast<const int2*>(a.fixrank)[c];
+            if (PHASE != 2) {
+                hp[k] = reinterpret_cast<const double2*>(a.Hp)[c];
+                w[k] = reinterpret_cast<const double2*>(a.w)[c];
+                wl[k] = reinterpret_cast<const double2*>(a.wl)[c];
+                wu[k] = reinterpret_cast<const double2*>(a.wu)[c];
+            } else {
+                v[k] = reinterpret_cast<const double2*>(a.v)[c];
+            }
+            if (PHASE == 0 && a.fixrank != nullptr) fr[k] = reinterpret_cast<const int2*>(a.fixrank)[c];
         }
     }
-    // pHp = dot(p,Hp) (:723); gamma = factor_to_boundary(p,w,w_l,w_u) (:728,:734).  Padding elements are zeros: no effect.
-    OpMinNan opmin;
-    double sum = 0.0, gmin = INF;
-#pragma unroll
-    for (int k = 0; k < CH; ++k) {
-        sum = fma(p[k].x, hp[k].x, sum);
-        sum = fma(p[k].y, hp[k].y, sum);
-        gmin = opmin(gmin, f2b_term(p[k].x, w[k].x, wl[k].x, wu[k].x, a.atol_f2b));
-        gmin = opmin(gmin, f2b_term(p[k].y, w[k].y, wl[k].y, wu[k].y, a.atol_f2b));
-    }
-    sum = wave_sum(sum);
-    gmin = wave_min(gmin);
-    if (lane == 0) { scratch[wave] = sum; scratch[NW + wave] = gmin; }
-    __syncthreads();
-    double pHp = 0.0, gamma = INF;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) { pHp += scratch[i]; gamma = opmin(gamma, scratch[NW + i]); }
-    __syncthreads();   // scratch is reused below
 
     int cont = 0, neg = 0, outside = 0;
-    double step = 0.0, alpha = QNAN;
+    double pHp = 0.0, gamma = INF, step = 0.0, alpha = QNAN;
     bool add_w = true;
-    if (pHp <= a.atol_neg) {                        // :725
-        neg = 1;
-        if (fabs(pHp) > a.atol_neg) step = gamma;   // :727-729
-        else add_w = false;
-    } else {
-        alpha = __ddiv_rn(rtv, pHp);                // :733
-        outside = alpha > gamma;                    // :735
-        if (outside) step = gamma;                  // :737
-        else { step = alpha; cont = 1; }            // :739
-    }
-    if (add_w) {
+    if (PHASE != 2) {
+        // pHp = dot(p,Hp) (:723); gamma = factor_to_boundary(p,w,w_l,w_u) (:728,:734).  Padding elements are zeros: no effect.
+        OpMinNan opmin;
+        double sum = 0.0, gmin = INF;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            w[k].x = __dadd_rn(w[k].x, __dmul_rn(step, p[k].x));
-            w[k].y = __dadd_rn(w[k].y, __dmul_rn(step, p[k].y));
+            sum = fma(p[k].x, hp[k].x, sum);
+            sum = fma(p[k].y, hp[k].y, sum);
+            gmin = opmin(gmin, f2b_term(p[k].x, w[k].x, wl[k].x, wu[k].x, a.atol_f2b));
+            gmin = opmin(gmin, f2b_term(p[k].y, w[k].y, wl[k].y, wu[k].y, a.atol_f2b));
         }
+        sum = wave_sum(sum);
+        gmin = wave_min(gmin);
+        if (lane == 0) { scratch[wave] = sum; scratch[NW + wave] = gmin; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { pHp += scratch[i]; gamma = opmin(gamma, scratch[NW + i]); }
+        __syncthreads();   // scratch is reused below
+
+        if (pHp <= a.atol_neg) {                        // :725
+            neg = 1;
+            if (fabs(pHp) > a.atol_neg) step = gamma;   // :727-729
+            else add_w = false;
+        } else {
+            alpha = __ddiv_rn(rtv, pHp);                // :733  (rtv == dot(r,v) bit for bit: deterministic dot)
+            outside = alpha > gamma;                    // :735
+            if (outside) step = gamma;                  // :737
+            else { step = alpha; cont = 1; }            // :739
+        }
+        if (add_w) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                w[k].x = __dadd_rn(w[k].x, __dmul_rn(step, p[k].x));
+                w[k].y = __dadd_rn(w[k].y, __dmul_rn(step, p[k].y));
+            }
+        }
+        if (cont) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                r[k].x = __dadd_rn(r[k].x, __dmul_rn(alpha, hp[k].x));     // :740
+                r[k].y = __dadd_rn(r[k].y, __dmul_rn(alpha, hp[k].y));
+                if (PHASE == 0) {
+                    v[k].x = (fr[k].x >= 0) ? 0.0 : r[k].x;                // projection!, box case (:741)
+                    v[k].y = (fr[k].y >= 0) ? 0.0 : r[k].y;
+                }
+            }
+        }
+    } else {
+        cont = 1;
+        pHp = st->pHp; gamma = st->gamma; alpha = st->alpha;
     }
+
     double rtv_next = rtv, beta = 0.0;
-    double2 v[CH];
-    if (cont) {
+    if (cont && PHASE != 1) {
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            r[k].x = __dadd_rn(r[k].x, __dmul_rn(alpha, hp[k].x));     // :740
-            r[k].y = __dadd_rn(r[k].y, __dmul_rn(alpha, hp[k].y));
-            v[k].x = (fr[k].x >= 0) ? 0.0 : r[k].x;                    // projection!, box case (:741)
-            v[k].y = (fr[k].y >= 0) ? 0.0 : r[k].y;
-            acc = fma(r[k].x, v[k].x, acc);                            // :743
+            acc = fma(r[k].x, v[k].x, acc);                                // :743
             acc = fma(r[k].y, v[k].y, acc);
         }
         acc = wave_sum(acc);
@@ -655,10 +681,10 @@ __global__ __launch_bounds__(CG_T) void cg_step_box_reg_kernel(CgArgs a) {
         rtv_next = 0.0;
 #pragma unroll
         for (int i = 0; i < NW; ++i) rtv_next += scratch[i];
-        beta = __ddiv_rn(rtv_next, rtv);                               // :744
+        beta = __ddiv_rn(rtv_next, rtv);                                   // :744
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            p[k].x = __dadd_rn(-v[k].x, __dmul_rn(beta, p[k].x));      // :745
+            p[k].x = __dadd_rn(-v[k].x, __dmul_rn(beta, p[k].x));          // :745
             p[k].y = __dadd_rn(-v[k].y, __dmul_rn(beta, p[k].y));
         }
     }
@@ -669,34 +695,45 @@ __global__ __launch_bounds__(CG_T) void cg_step_box_reg_kernel(CgArgs a) {
         if (!act[k]) continue;
         const bool full = (2 * c + 1) < a.n;
         if (full) {
-            if (add_w) reinterpret_cast<double2*>(a.w)[c] = w[k];
+            if (PHASE != 2 && add_w) reinterpret_cast<double2*>(a.w)[c] = w[k];
             if (cont) {
-                reinterpret_cast<double2*>(a.r)[c] = r[k];
-                reinterpret_cast<double2*>(a.v)[c] = v[k];
-                reinterpret_cast<double2*>(a.p)[c] = p[k];
+                if (PHASE != 2) reinterpret_cast<double2*>(a.r)[c] = r[k];
+                if (PHASE == 0) reinterpret_cast<double2*>(a.v)[c] = v[k];
+                if (PHASE != 1) reinterpret_cast<double2*>(a.p)[c] = p[k];
             }
         } else {
-            if (add_w) a.w[2 * c] = w[k].x;
-            if (cont) { a.r[2 * c] = r[k].x; a.v[2 * c] = v[k].x; a.p[2 * c] = p[k].x; }
+            if (PHASE != 2 && add_w) a.w[2 * c] = w[k].x;
+            if (cont) {
+                if (PHASE != 2) a.r[2 * c] = r[k].x;
+                if (PHASE == 0) a.v[2 * c] = v[k].x;
+                if (PHASE != 1) a.p[2 * c] = p[k].x;
+            }
         }
     }
     if (tid == 0) {
-        const int n_hmul = n_hmul0 + 1;
-        st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = n_hmul;
-        st->neg_curvature = neg; st->outside_region = outside; st->need_proj = 0;
-        double tr_gamma = (neg && !add_w) ? QNAN : gamma;
-        if (!cont) {
-            st->done = 1;
-            st->status = cg_final_status(st);
-        } else {
-            st->beta = beta; st->rtv = rtv_next;                       // :746
-            st->approx_solved = fabs(rtv_next) < tol_cg;               // :747
-            st->iter = iter0 + 1;                                      // :748
-            if (st->approx_solved || st->iter > max_iter) { st->done = 1; st->status = cg_final_status(st); }
+        const int n_hmul = (PHASE == 2) ? n_hmul0 : n_hmul0 + 1;
+        bool write_trace = false;
+        if (PHASE != 2) {
+            st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = n_hmul;
+            st->neg_curvature = neg; st->outside_region = outside;
+            st->need_proj = (PHASE == 1 && cont) ? 1 : 0;
+            if (!cont) {
+                st->done = 1;
+                st->status = cg_final_status(st);
+                write_trace = true;
+            }
         }
-        if (a.trace != nullptr && n_hmul <= a.trace_cap) {
+        if (cont && PHASE != 1) {
+            st->beta = beta; st->rtv = rtv_next;                           // :746
+            st->approx_solved = fabs(rtv_next) < tol_cg;                   // :747
+            st->iter = iter0 + 1;                                          // :748
+            st->need_proj = 0;
+            if (st->approx_solved || st->iter > max_iter) { st->done = 1; st->status = cg_final_status(st); }
+            write_trace = true;
+        }
+        if (write_trace && a.trace != nullptr && n_hmul <= a.trace_cap) {
             double* row = a.trace + 4 * (int64_t)(n_hmul - 1);
-            row[0] = pHp; row[1] = alpha; row[2] = tr_gamma; row[3] = rtv_next;
+            row[0] = pHp; row[1] = alpha; row[2] = (PHASE != 2 && neg && !add_w) ? QNAN : gamma; row[3] = rtv_next;
         }
     }
 }
@@ -877,6 +914,79 @@ __global__ __launch_bounds__(CG_T) void chol_lower_kernel(double* __restrict__ M
         }
         __syncthreads();
     }
+}
+
+// Reduced-form factor for mA <= 64: one wave, lane i owns row i of M in registers; right-looking Cholesky with
+// v_readlane broadcasts (no LDS, no barriers).  Writes L (lower, column-major m x m) and the reciprocal diagonal
+// dinv[m] right after the matrix (M + m*m), which turns the substitutions' divisions into multiplications.
+__global__ __launch_bounds__(64) void chol_small_kernel(double* __restrict__ M, int m, int* info) {
+    const int lane = threadIdx.x;
+    double a[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) a[k] = (lane < m && k <= lane && k < m) ? M[lane + (int64_t)k * m] : 0.0;
+    int bad = 0;
+    double dinv_mine = 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (j < m) {
+            const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[j]), j),
+                                                __builtin_amdgcn_readlane(__double2loint(a[j]), j));
+            if (!(ajj > 0.0) && bad == 0) bad = j + 1;
+            const double d = sqrt(ajj);
+            const double inv = 1.0 / d;
+            if (lane == j) { a[j] = d; dinv_mine = inv; }
+            else if (lane > j) a[j] = a[j] / d;
+#pragma unroll
+            for (int k = j + 1; k < 64; ++k) {
+                if (k < m) {
+                    const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[j]), k),
+                                                        __builtin_amdgcn_readlane(__double2loint(a[j]), k));
+                    if (lane >= k) a[k] = fma(-a[j], lkj, a[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+        if (lane < m && k <= lane && k < m) M[lane + (int64_t)k * m] = a[k];
+    if (lane < m) M[(int64_t)m * m + lane] = dinv_mine;
+    if (lane == 0) info[0] = bad;
+}
+
+// tw <- L' \ (L \ tw) for m <= 64 (reduced form): one wave, row i and column i of L in registers, reciprocal diagonal
+// from chol_small_kernel; 2 x 64 dependent steps of readlane + mul + fma.
+__global__ __launch_bounds__(64) void trsv_small_kernel(ProjArgs a) {
+    if (proj_skip(a.state)) return;
+    const int lane = threadIdx.x, m = a.mpp;
+    const double* __restrict__ L = a.L;
+    const double* __restrict__ dinv = a.L + (int64_t)m * m;
+    double Lrow[64], Lcol[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        Lrow[k] = (lane < m && k < lane) ? L[lane + (int64_t)k * m] : 0.0;      // L[i][k], k < i
+        Lcol[k] = (lane < m && k > lane && k < m) ? L[k + (int64_t)lane * m] : 0.0;   // L[k][i], k > i
+    }
+    const double di = (lane < m) ? dinv[lane] : 0.0;
+    double xi = (lane < m) ? a.tw[lane] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        if (j < m) {
+            if (lane == j) xi = xi * di;
+            const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
+                                               __builtin_amdgcn_readlane(__double2loint(xi), j));
+            if (lane > j) xi = fma(-Lrow[j], xj, xi);
+        }
+    }
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+        if (j < m) {
+            if (lane == j) xi = xi * di;
+            const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
+                                               __builtin_amdgcn_readlane(__double2loint(xi), j));
+            if (lane < j) xi = fma(-Lcol[j], xj, xi);
+        }
+    }
+    if (lane < m) a.tw[lane] = xi;
 }
 
 // tw <- L' \ (L \ tw)   (:114-115, :132-133).  Single workgroup, 64-wide blocked substitution;

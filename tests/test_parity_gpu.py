@@ -466,3 +466,25 @@ bh._lib.lib().bh_comm_destroy()
     assert out.returncode == 0, out.stderr[-2000:]
     tok = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("OK")][-1].split()    # RCCL prints a banner first
     assert tok[0] == "OK" and int(tok[1]) >= 3 + int(tok[2])      # hmul + jtv + vthv + one per H*p of the CG run
+
+
+def test_workspace_reuse_across_sizes_and_odd_n(bh):
+    """The CG workspace is shared by all calls: a larger problem must not leak into the padding of a later smaller / odd-n
+    one (box and general path)."""
+    rng = np.random.default_rng(42)
+    for n, mA in [(96, 0), (33, 0), (95, 3), (17, 0), (64, 2), (5, 1), (3, 0)]:
+        d = 3 * n
+        J = rng.standard_normal((d, n)) / np.sqrt(d)
+        A = rng.standard_normal((mA, n))
+        fix = np.zeros(n, dtype=bool)
+        fix[rng.choice(n, max(n // 6, 0), replace=False)] = True
+        cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix if fix.any() else None, l=-np.ones(n), u=np.ones(n))
+        g = rng.standard_normal(n)
+        w_l, w_u = R.build_step_bounds(np.where(fix, 1.0, 0.0), cons_o, 0.5)
+        Ho = R.AlHessian(J, np.zeros((0, n)), 1.0)
+        w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+        H = bh.AlHessian(J, None, 1.0)
+        cons = bh.MixedConstraints(A, cons_o.chol_L, fix)
+        w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
+        assert int(status) == int(s_ref) and info["iters"] == it_ref, (n, mA)
+        assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), (n, mA)
