@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>   // types only: librccl is dlopen'ed in bh_comm_init (never needed on one GPU)
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -24,10 +25,13 @@ namespace {
 struct CgWorkspace {
     int64_t n_pad = 0;
     double *w = nullptr, *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr, *g = nullptr, *wl = nullptr, *wu = nullptr;
+    double *x = nullptr, *s = nullptr, *xlow = nullptr, *xupp = nullptr;   // minor_iterate staging
     double* slab = nullptr;
+    double* scalars = nullptr;     // 8 doubles (linesearch alpha, ...)
     CgState* d_state = nullptr;
-    CgState* h_state = nullptr;   // pinned, 2 slots
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    volatile unsigned long long* h_mirror = nullptr;   // host-mapped progress word written by the CG kernels
+    unsigned long long* d_mirror = nullptr;            // its device address
+    unsigned tag = 0;
     double* d_trace = nullptr;
     int64_t trace_cap = 0;
 };
@@ -172,7 +176,7 @@ int grid_for(int cfg, int64_t nrows) {
 }
 
 constexpr int kEvCap = 512;
-constexpr int kEvStride = 4;
+constexpr int kEvStride = 8;
 
 }  // namespace
 
@@ -194,6 +198,8 @@ struct bh_hess {
     int last_n_hmul = 0;           // H*p count of the previous bh_pcg on this handle (launch schedule hint)
     bh_stats_t stats{};
     std::vector<hipEvent_t> ev;    // 2*kEvCap, created lazily
+    std::vector<int> ev_pending;   // launch index (within the running bh_pcg) of each recorded pair
+    uint64_t hmul_seq = 0;         // H*p launches of bh_pcg calls on this handle (profile sampling)
 };
 
 struct bh_proj {
@@ -220,19 +226,24 @@ namespace {
 int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
     CgWorkspace& c = g_ctx.cg;
     if (c.n_pad < n_pad) {
-        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.g, &c.wl, &c.wu};
+        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.g, &c.wl, &c.wu, &c.x, &c.s, &c.xlow, &c.xupp};
         dev_free(c.slab);
         c.slab = nullptr;
-        BH_TRY(dev_alloc(&c.slab, 8 * n_pad));
-        BH_HIP(hipMemsetAsync(c.slab, 0, (size_t)8 * n_pad * sizeof(double), g_ctx.stream));
-        for (int i = 0; i < 8; ++i) *vecs[i] = c.slab + (int64_t)i * n_pad;
+        BH_TRY(dev_alloc(&c.slab, 12 * n_pad + 8));
+        BH_HIP(hipMemsetAsync(c.slab, 0, (size_t)(12 * n_pad + 8) * sizeof(double), g_ctx.stream));
+        for (int i = 0; i < 12; ++i) *vecs[i] = c.slab + (int64_t)i * n_pad;
+        c.scalars = c.slab + 12 * n_pad;
         c.n_pad = n_pad;
     }
     if (!c.d_state) {
         BH_TRY(dev_alloc(&c.d_state, 1));
-        BH_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.h_state), 2 * sizeof(CgState), hipHostMallocDefault));
-        BH_HIP(hipEventCreateWithFlags(&c.ev[0], hipEventDisableTiming));
-        BH_HIP(hipEventCreateWithFlags(&c.ev[1], hipEventDisableTiming));
+        void* hp = nullptr;
+        BH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        memset(hp, 0, 64);
+        c.h_mirror = reinterpret_cast<volatile unsigned long long*>(hp);
+        void* dp = nullptr;
+        BH_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        c.d_mirror = reinterpret_cast<unsigned long long*>(dp);
     }
     if (trace_cap > c.trace_cap) {
         dev_free(c.d_trace);
@@ -241,6 +252,31 @@ int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
         c.trace_cap = trace_cap;
     }
     return BH_OK;
+}
+
+struct MirrorWord { int done, status, iter, n_hmul; };
+
+// Spin on the host-mapped progress word until this call's tag shows `done` or at least `target` H*p products.
+int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long spins = 0;
+    while (true) {
+        const unsigned long long w = *c.h_mirror;
+        if (((w >> 48) & 0xffffu) == (tag & 0xffffu)) {
+            out->status = (int)((w >> 44) & 0xf);
+            out->done = (int)((w >> 40) & 0xf);
+            out->iter = (int)((w >> 20) & 0xfffff);
+            out->n_hmul = (int)(w & 0xfffff);
+            if (out->done || out->n_hmul >= target) return BH_OK;
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0xffff) == 0) {
+            hipError_t q = hipStreamQuery(g_ctx.stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(BH_ERR_HIP, std::string("CG loop: ") + hipGetErrorString(q));
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return fail(BH_ERR_HIP, "CG loop: no progress for 120 s");
+        }
+    }
 }
 
 int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H) {
@@ -259,18 +295,24 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
     a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
     a.v = v_pad; a.u = nullptr; a.t_out = nullptr; a.partials = H->partials; a.sq_partials = nullptr;
     a.mu = H->mu; a.state = state; a.reverse = reverse;
-    // BH_FLAG_PROFILE: hipEvents around every kEvStride-th H*p launch (an event pair costs ~9 us of stream time, so
-    // timing every launch would slow the loop it measures by 2.5 %).
-    const bool timed = (g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0 && (ev_index % kEvStride) == 0 && (ev_index / kEvStride) < kEvCap;
-    if (timed) {
-        if (H->ev.empty()) {
-            H->ev.resize(2 * kEvCap, nullptr);
-            for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
+    // BH_FLAG_PROFILE: hipEvents around every kEvStride-th H*p launch of this handle, counted ACROSS calls (an event pair
+    // costs ~10 us of stream time; timing every launch would slow the loop it measures by 3 %).
+    bool timed = false;
+    int slot = -1;
+    if ((g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0) {
+        if ((H->hmul_seq++ % kEvStride) == 0 && (int)H->ev_pending.size() < kEvCap) {
+            if (H->ev.empty()) {
+                H->ev.resize(2 * kEvCap, nullptr);
+                for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
+            }
+            slot = (int)H->ev_pending.size();
+            H->ev_pending.push_back(ev_index);
+            timed = true;
+            BH_HIP(hipEventRecord(H->ev[2 * slot], g_ctx.stream));
         }
-        BH_HIP(hipEventRecord(H->ev[2 * (ev_index / kEvStride)], g_ctx.stream));
     }
     launch_row_stream(cfg, MODE_FUSED, a, grid, g_ctx.stream);
-    if (timed) BH_HIP(hipEventRecord(H->ev[2 * (ev_index / kEvStride) + 1], g_ctx.stream));
+    if (timed) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], g_ctx.stream));
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
                        H->partials, H->ld, H->nchunks, grid, z_out, state);
     BH_HIP(hipGetLastError());
@@ -295,9 +337,9 @@ int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_ro
     return BH_OK;
 }
 
-int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out) {
+int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out, bool with_c_rows = false) {
     const int cfg = pick_config(H->nchunks);
-    const int64_t nrows = H->d;
+    const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
     const int grid = grid_for(cfg, nrows);
     RowStreamArgs a{};
     a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
@@ -477,9 +519,7 @@ int32_t bh_shutdown(void) {
     if (g_ctx.comm && g_ctx.p_ncclCommDestroy) { g_ctx.p_ncclCommDestroy(g_ctx.comm); g_ctx.comm = nullptr; }
     CgWorkspace& c = g_ctx.cg;
     dev_free(c.slab); dev_free(c.d_state); dev_free(c.d_trace);
-    if (c.h_state) (void)hipHostFree(c.h_state);
-    if (c.ev[0]) (void)hipEventDestroy(c.ev[0]);
-    if (c.ev[1]) (void)hipEventDestroy(c.ev[1]);
+    if (c.h_mirror) (void)hipHostFree(const_cast<unsigned long long*>(c.h_mirror));
     c = CgWorkspace();
     dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
@@ -872,41 +912,29 @@ int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
 }
 
 // ---- projected_cg ---------------------------------------------------------------------------
-static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l, const double* w_u, double kappa2,
-                        double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters, double* trace,
-                        int64_t trace_cap, int32_t* n_hmul_out, bool dev) {
-    BH_REQUIRE_INIT();
-    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
-    BH_TRY(check_proj_ready(P));
-    if (!g_minor || !w_l || !w_u || !w_out) return fail(BH_ERR_INVALID_ARG, "NULL vector argument");
-    if (H->n != P->n) return fail(BH_ERR_SHAPE, "H.n != lincons.n");
-    if (trace == nullptr) trace_cap = 0;
-    if (trace_cap < 0) return fail(BH_ERR_INVALID_ARG, "negative trace_cap");
+struct PcgFin { int done, status, iter, n_hmul; };
+
+// Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
+// still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
+static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* wlp, const double* wup, double* wp, bool w_in_ws,
+                       double kappa2, double atol_negcurv, double atol_f2b, int64_t trace_cap, PcgFin* fin_out) {
     const int64_t n = H->n, n_pad = H->ld;
     const int64_t max_iter64 = 2 * (n - P->mA - P->nfix);   // src/basic_tralcnlss.jl:714
     if (max_iter64 < 0) return fail(BH_ERR_PRECONDITION, "n - mA - count(fixvars) < 0");
     const int max_iter = (int)std::min<int64_t>(max_iter64, 0x7fffffff);
-    BH_TRY(ensure_cg_workspace(n_pad, trace_cap));
     CgWorkspace& c = g_ctx.cg;
+    H->ev_pending.clear();
     hipStream_t s = g_ctx.stream;
-
-    // Device callers with even n hand over buffers the kernels can use in place (16-byte chunk loads stay in bounds);
-    // host callers and odd n go through the zero-padded workspace.
-    const bool in_place = dev && (n % 2 == 0);
-    const double *gp = g_minor, *wlp = w_l, *wup = w_u;
-    double* wp = w_out;
-    if (!in_place) {
-        BH_TRY(stage_vec(c.g, g_minor, n, dev));
-        BH_TRY(stage_vec(c.wl, w_l, n, dev));
-        BH_TRY(stage_vec(c.wu, w_u, n, dev));
-        gp = c.g; wlp = c.wl; wup = c.wu; wp = c.w;
-    }
+    const bool in_place = !w_in_ws;
 
     CgArgs a{};
     a.st = c.d_state; a.w = wp; a.r = c.r; a.v = c.v; a.p = c.p; a.Hp = c.Hp; a.g = gp; a.wl = wlp; a.wu = wup;
     a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
     a.n = (int)n; a.n_pad = (int)n_pad; a.w_in_ws = in_place ? 0 : 1; a.max_iter = max_iter; a.kappa2 = kappa2; a.atol_neg = atol_negcurv; a.atol_f2b = atol_f2b;
     a.trace = trace_cap > 0 ? c.d_trace : nullptr; a.trace_cap = (int)std::min<int64_t>(trace_cap, 0x7fffffff);
+    c.tag = (c.tag + 1) & 0xffffu;
+    if (c.tag == 0) c.tag = 1;
+    a.mirror = c.d_mirror; a.tag = c.tag;
 
     const bool box = (P->mA == 0);
     if (box) {
@@ -935,52 +963,89 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     // (consecutive subproblems of a minor loop behave alike), then, if the loop is still running, launch-ahead batches:
     // batch k+1 is enqueued before the host looks at batch k's state, so the GPU never waits for the host.
     const int batch = (int)g_ctx.opt_batch;
-    int launched = 0, k = 0;
-    auto launch_batch = [&](int slot, int nb) -> int32_t {
+    int launched = 0;
+    auto launch_batch = [&](int nb) -> int32_t {
         nb = std::min(nb, max_iter - launched);
         for (int i = 0; i < nb; ++i) BH_TRY(launch_iteration(launched + i));
         launched += nb;
-        BH_HIP(hipMemcpyAsync(&c.h_state[slot], c.d_state, sizeof(CgState), hipMemcpyDeviceToHost, s));
-        BH_HIP(hipEventRecord(c.ev[slot], s));
         return BH_OK;
     };
+    // Progress comes back through one host-mapped 8-byte word the kernels store to (no copy kernels, no events).
+    MirrorWord mw{};
     const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, 8) : std::min(batch, 2);
-    BH_TRY(launch_batch(0, first));
-    BH_HIP(hipEventSynchronize(c.ev[0]));
-    if (!c.h_state[0].done && launched < max_iter) {
-        BH_TRY(launch_batch(0, batch));
+    BH_TRY(launch_batch(first));
+    BH_TRY(wait_mirror(c, a.tag, launched, &mw));
+    if (!mw.done && launched < max_iter) {
+        int target = launched;
+        BH_TRY(launch_batch(batch));
         while (true) {
+            target = launched;                       // everything enqueued so far except the batch launched next
             const bool more = launched < max_iter;
-            if (more) BH_TRY(launch_batch((k + 1) & 1, batch));
-            BH_HIP(hipEventSynchronize(c.ev[k & 1]));
-            if (c.h_state[k & 1].done || !more) break;
-            ++k;
+            if (more) BH_TRY(launch_batch(batch));
+            BH_TRY(wait_mirror(c, a.tag, target, &mw));
+            if (mw.done || !more) break;
         }
+        if (!mw.done) BH_TRY(wait_mirror(c, a.tag, launched, &mw));
     }
-    BH_HIP(hipMemcpyAsync(&c.h_state[0], c.d_state, sizeof(CgState), hipMemcpyDeviceToHost, s));
-    if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
-    if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, s));
-    BH_HIP(hipStreamSynchronize(s));
-    const CgState fin = c.h_state[0];
+    fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
+    return BH_OK;
+}
+
+// After the caller's hipStreamSynchronize: bookkeeping of one finished projected_cg.
+static int32_t pcg_finish(bh_hess* H, const PcgFin& fin) {
     if (!fin.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
-    if (status) *status = fin.status;
-    if (iters) *iters = fin.iter;
-    if (n_hmul_out) *n_hmul_out = fin.n_hmul;
     H->stats.n_pcg += 1;
     H->last_n_hmul = fin.n_hmul;
     H->stats.n_hmul += fin.n_hmul;
     H->stats.n_cg_iter += fin.iter - 1;
     H->stats.n_proj += fin.iter;
-    if ((g_ctx.flags & BH_FLAG_PROFILE) && !H->ev.empty()) {
-        const int m = std::min((fin.n_hmul + kEvStride - 1) / kEvStride, kEvCap);   // launches 0, 4, 8, ... that really ran
-        for (int i = 0; i < m; ++i) {
+    if (!H->ev_pending.empty()) {
+        for (size_t i = 0; i < H->ev_pending.size(); ++i) {
+            if (H->ev_pending[i] >= fin.n_hmul) continue;         // an over-launched no-op: not an H*p
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, H->ev[2 * i], H->ev[2 * i + 1]) == hipSuccess) {
                 H->stats.hmul_ms += ms;
                 H->stats.hmul_timed += 1;
             }
         }
+        H->ev_pending.clear();
     }
+    return BH_OK;
+}
+
+static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l, const double* w_u, double kappa2,
+                        double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters, double* trace,
+                        int64_t trace_cap, int32_t* n_hmul_out, bool dev) {
+    BH_REQUIRE_INIT();
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    BH_TRY(check_proj_ready(P));
+    if (!g_minor || !w_l || !w_u || !w_out) return fail(BH_ERR_INVALID_ARG, "NULL vector argument");
+    if (H->n != P->n) return fail(BH_ERR_SHAPE, "H.n != lincons.n");
+    if (trace == nullptr) trace_cap = 0;
+    if (trace_cap < 0) return fail(BH_ERR_INVALID_ARG, "negative trace_cap");
+    const int64_t n = H->n;
+    BH_TRY(ensure_cg_workspace(H->ld, trace_cap));
+    CgWorkspace& c = g_ctx.cg;
+    // Device callers with even n hand over buffers the kernels can use in place (16-byte chunk loads stay in bounds);
+    // host callers and odd n go through the zero-padded workspace.
+    const bool in_place = dev && (n % 2 == 0);
+    const double *gp = g_minor, *wlp = w_l, *wup = w_u;
+    double* wp = w_out;
+    if (!in_place) {
+        BH_TRY(stage_vec(c.g, g_minor, n, dev));
+        BH_TRY(stage_vec(c.wl, w_l, n, dev));
+        BH_TRY(stage_vec(c.wu, w_u, n, dev));
+        gp = c.g; wlp = c.wl; wup = c.wu; wp = c.w;
+    }
+    PcgFin fin{};
+    BH_TRY(pcg_run(H, P, gp, wlp, wup, wp, !in_place, kappa2, atol_negcurv, atol_f2b, trace_cap, &fin));
+    if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
+    if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));      // drains the over-launched no-op kernels; orders w for any consumer
+    BH_TRY(pcg_finish(H, fin));
+    if (status) *status = fin.status;
+    if (iters) *iters = fin.iter;
+    if (n_hmul_out) *n_hmul_out = fin.n_hmul;
     return BH_OK;
 }
 
@@ -995,6 +1060,112 @@ int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const doub
                    int64_t trace_cap, int32_t* n_hmul) {
     return pcg_impl(H, P, g_minor_dev, w_l_dev, w_u_dev, kappa2, atol_negcurv, atol_f2b, w_out_dev, status, iters, trace, trace_cap,
                     n_hmul, true);
+}
+
+
+// linesearch(g_model, H, w, w_l, w_u, fix_bounds) — src/basic_tralcnlss.jl:766-791 (device part shared with bh_minor_iterate):
+// wHw = vthv(H, w_pad) -> H->scalar (all-reduced), then alpha -> c.scalars[0]; optionally w_pad *= alpha.
+static int32_t launch_linesearch(bh_hess* H, bh_proj* P, const double* g_dev, double* w_pad, const double* wl_dev, const double* wu_dev,
+                                 bool scale_w) {
+    CgWorkspace& c = g_ctx.cg;
+    BH_TRY(launch_jv(H, w_pad, nullptr, true, H->scalar));
+    BH_TRY(allreduce_inplace(H->scalar, 1, H));
+    hipLaunchKernelGGL(linesearch_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, g_dev, w_pad, wl_dev, wu_dev,
+                       P->nfix > 0 ? P->fixrank : (const int*)nullptr, (const double*)H->scalar, (int)H->n, scale_w ? 1 : 0, c.scalars);
+    BH_HIP(hipGetLastError());
+    H->stats.n_jv += 1;
+    return BH_OK;
+}
+
+int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const double* w, const double* w_l, const double* w_u,
+                      double* alpha_out) {
+    BH_REQUIRE_INIT();
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    BH_TRY(check_proj_ready(P));
+    if (!g_model || !w || !w_l || !w_u || !alpha_out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    if (H->n != P->n) return fail(BH_ERR_SHAPE, "H.n != lincons.n");
+    const int64_t n = H->n;
+    BH_TRY(ensure_cg_workspace(H->ld, 0));
+    CgWorkspace& c = g_ctx.cg;
+    BH_HIP(hipMemsetAsync(c.w, 0, (size_t)H->ld * sizeof(double), g_ctx.stream));
+    BH_TRY(stage_vec(c.w, w, n, false));
+    BH_TRY(stage_vec(c.g, g_model, n, false));
+    BH_TRY(stage_vec(c.wl, w_l, n, false));
+    BH_TRY(stage_vec(c.wu, w_u, n, false));
+    BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, false));
+    BH_TRY(fetch_vec(alpha_out, c.scalars, 1, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+
+// minor_iterate(x, s, g_model, H, lincons, delta, kappa2) — src/basic_tralcnlss.jl:649-675, entirely on the device:
+// step bounds (:660-665), projected_cg (:667), linesearch + scaling (:669-672).
+int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* s_vec, const double* g_model, const double* xlow,
+                         const double* xupp, double delta, double kappa2, double atol_negcurv, double atol_f2b, double* w_out,
+                         int32_t* status, int32_t* iters, int32_t* n_hmul_out, double* alpha_out) {
+    BH_REQUIRE_INIT();
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    BH_TRY(check_proj_ready(P));
+    if (!x || !s_vec || !g_model || !xlow || !xupp || !w_out) return fail(BH_ERR_INVALID_ARG, "NULL vector argument");
+    if (H->n != P->n) return fail(BH_ERR_SHAPE, "H.n != lincons.n");
+    const int64_t n = H->n;
+    BH_TRY(ensure_cg_workspace(H->ld, 0));
+    CgWorkspace& c = g_ctx.cg;
+    BH_TRY(stage_vec(c.x, x, n, false));
+    BH_TRY(stage_vec(c.s, s_vec, n, false));
+    BH_TRY(stage_vec(c.g, g_model, n, false));
+    BH_TRY(stage_vec(c.xlow, xlow, n, false));
+    BH_TRY(stage_vec(c.xupp, xupp, n, false));
+    const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
+    hipLaunchKernelGGL(step_bounds_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, c.x, c.s, c.xlow, c.xupp,
+                       P->nfix > 0 ? P->fixrank : (const int*)nullptr, delta, (int)n, c.wl, c.wu);
+    PcgFin fin{};
+    BH_TRY(pcg_run(H, P, c.g, c.wl, c.wu, c.w, true, kappa2, atol_negcurv, atol_f2b, 0, &fin));
+    double alpha = std::nan("");
+    const bool do_ls = fin.status != BH_CG_NEGATIVE_CURVATURE;       // :669
+    if (do_ls) {
+        BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, true));
+        BH_TRY(fetch_vec(&alpha, c.scalars, 1, false));
+    }
+    BH_TRY(fetch_vec(w_out, c.w, n, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(pcg_finish(H, fin));
+    if (status) *status = fin.status;
+    if (iters) *iters = fin.iter;
+    if (n_hmul_out) *n_hmul_out = fin.n_hmul;
+    if (alpha_out) *alpha_out = alpha;
+    return BH_OK;
+}
+
+// g = Jx'*rx + Cx'*y_bar — src/basic_tralcnlss.jl:45,:74 (r = this rank's d rows; C'y_bar added by rank 0; all-reduced).
+int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out) {
+    BH_REQUIRE_INIT();
+    if (!H || (!r && H->d > 0) || (!ybar && H->q > 0) || !g_out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(H->upad, r, H->d, false));
+    BH_TRY(stage_vec(H->upad + H->d, ybar, H->q, false));
+    BH_TRY(launch_jtv(H, H->upad, H->zpad, true));
+    BH_TRY(fetch_vec(g_out, H->zpad, H->n, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    H->stats.n_jtv += 1;
+    return BH_OK;
+}
+
+// g_minor = H*s + g — src/basic_tralcnlss.jl:412,:437.
+int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* out_n) {
+    BH_REQUIRE_INIT();
+    if (!H || !s_vec || !g || !out_n) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    const int64_t n = H->n;
+    BH_TRY(ensure_cg_workspace(H->ld, 0));
+    CgWorkspace& c = g_ctx.cg;
+    BH_TRY(stage_vec(H->vpad, s_vec, n, false));
+    BH_TRY(stage_vec(c.g, g, n, false));
+    BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
+    const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
+    hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, (const double*)c.g, H->zpad, (int)n);
+    BH_TRY(fetch_vec(out_n, H->zpad, n, false));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    H->stats.n_hmul += 1;
+    return BH_OK;
 }
 
 int32_t bh_factor_to_boundary(const double* p, const double* w, const double* w_l, const double* w_u, int64_t n, double atol,

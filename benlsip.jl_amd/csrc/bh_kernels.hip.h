@@ -370,6 +370,8 @@ struct CgArgs {
     int max_iter;
     double kappa2, atol_neg, atol_f2b;
     double* trace; int trace_cap;
+    unsigned long long* mirror;   // host-mapped word the host polls instead of copying CgState back (NULL: none)
+    unsigned tag;                 // per-call tag stored in the mirror's top 16 bits
 };
 
 __device__ __forceinline__ double f2b_term(double p, double w, double wl, double wu, double atol) {
@@ -387,6 +389,16 @@ __device__ __forceinline__ int cg_final_status(const CgState* st) {
     if (st->neg_curvature) return 2;
     if (st->iter == st->max_iter) return 3;
     return 4;
+}
+
+// One 8-byte system-scope store to host-mapped memory: [tag:16 | status:4 | done:4 | iter:20 | n_hmul:20].  A single
+// naturally aligned word cannot tear, so the host needs no ordering beyond reading it.
+__device__ __forceinline__ void publish_state(const CgArgs& a, const CgState* st) {
+    if (a.mirror == nullptr) return;
+    const unsigned long long wv = ((unsigned long long)(a.tag & 0xffffu) << 48) | ((unsigned long long)(st->status & 0xf) << 44) |
+                                  ((unsigned long long)(st->done & 0xf) << 40) | ((unsigned long long)(st->iter & 0xfffff) << 20) |
+                                  (unsigned long long)(st->n_hmul & 0xfffff);
+    __hip_atomic_store(a.mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // w = 0; r = g  (:702-705).  With BOX: v = mask(r), then the tail of cg_init_finish.
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(CG_T) void cg_init_kernel(CgArgs a) {
             st->n_hmul = 0; st->need_proj = 0;
             st->done = (1 <= a.max_iter) ? 0 : 1;   // :720
             st->status = cg_final_status(st);
+            publish_state(a, st);
         }
     } else if (threadIdx.x == 0) {
         a.st->done = 0; a.st->need_proj = 1;
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(CG_T) void cg_init_finish_kernel(CgArgs a) {
         st->n_hmul = 0; st->need_proj = 0;
         st->done = (1 <= a.max_iter) ? 0 : 1;
         st->status = cg_final_status(st);
+        publish_state(a, st);
     }
 }
 
@@ -509,6 +523,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
                     double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
                     row[0] = pHp; row[1] = st->alpha; row[2] = (neg && !add_w) ? __longlong_as_double(0x7ff8000000000000ll) : gamma; row[3] = rtv;
                 }
+                publish_state(a, st);
             } else {
                 st->need_proj = 1;
             }
@@ -541,6 +556,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
                     double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
                     row[0] = st->pHp; row[1] = alpha; row[2] = st->gamma; row[3] = rtv_next;
                 }
+                publish_state(a, st);
             }
         } else {
             for (int i = tid; i < a.n; i += CG_T) a.r[i] = __dadd_rn(a.r[i], __dmul_rn(alpha, a.Hp[i]));
@@ -564,6 +580,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
                 double* row = a.trace + 4 * (int64_t)(st->n_hmul - 1);
                 row[0] = st->pHp; row[1] = alpha; row[2] = st->gamma; row[3] = rtv_next;
             }
+            publish_state(a, st);
         }
     }
 }
@@ -735,7 +752,63 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
             double* row = a.trace + 4 * (int64_t)(n_hmul - 1);
             row[0] = pHp; row[1] = alpha; row[2] = (PHASE != 2 && neg && !add_w) ? QNAN : gamma; row[3] = rtv_next;
         }
+        if (write_trace) publish_state(a, st);     // an iteration (or the whole loop) has completed
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Callers of projected_cg on the device.
+// ------------------------------------------------------------------------------------------
+// The w_l / w_u construction of minor_iterate — src/basic_tralcnlss.jl:660-665: +-Inf on the free variables,
+// min(xupp - (x+s), delta) / max(xlow - (x+s), -delta) on the fixed ones.
+__global__ __launch_bounds__(256) void step_bounds_kernel(const double* __restrict__ x, const double* __restrict__ s,
+                                                          const double* __restrict__ xlow, const double* __restrict__ xupp,
+                                                          const int* __restrict__ fixrank, double delta, int n,
+                                                          double* __restrict__ wl, double* __restrict__ wu) {
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        double lo = -INF, hi = INF;
+        if (fixrank != nullptr && fixrank[i] >= 0) {
+            const double xm = __dadd_rn(x[i], s[i]);           // x_minor = x + s  (:660)
+            hi = fmin(__dsub_rn(xupp[i], xm), delta);          // :664
+            lo = fmax(__dsub_rn(xlow[i], xm), -delta);         // :665
+        }
+        wl[i] = lo;
+        wu[i] = hi;
+    }
+}
+
+// linesearch — src/basic_tralcnlss.jl:766-791, given wHw = vthv(H,w) in wHw[0]; optionally scales w by alpha in place
+// (minor_iterate :670-671).  out[0] = alpha.  Single workgroup.
+__global__ __launch_bounds__(CG_T) void linesearch_kernel(const double* __restrict__ g, double* __restrict__ w,
+                                                          const double* __restrict__ wl, const double* __restrict__ wu,
+                                                          const int* __restrict__ fixrank, const double* __restrict__ wHw_p,
+                                                          int n, int scale_w, double* __restrict__ out) {
+    __shared__ double scratch[2 * (CG_T / 64)];
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    OpMinNan opmin;
+    double gw[1] = {0.0}, amin[1] = {INF};
+    for (int i = threadIdx.x; i < n; i += CG_T) {
+        const double wi = w[i];
+        gw[0] = fma(g[i], wi, gw[0]);
+        if (fixrank == nullptr || fixrank[i] < 0) {              // :781
+            if (wi < 0.0) amin[0] = opmin(amin[0], __ddiv_rn(wl[i], wi));      // :783
+            else if (wi > 0.0) amin[0] = opmin(amin[0], __ddiv_rn(wu[i], wi)); // :785
+        }
+    }
+    block_reduce<CG_T, 1>(gw, scratch, OpSum(), 0.0);
+    block_reduce<CG_T, 1>(amin, scratch, opmin, INF);
+    const double wHw = wHw_p[0];
+    const double alpha_opt = (wHw > 0.0) ? __ddiv_rn(-gw[0], wHw) : INF;      // :776
+    const double alpha = opmin(alpha_opt, amin[0]);                            // :790
+    if (scale_w)
+        for (int i = threadIdx.x; i < n; i += CG_T) w[i] = __dmul_rn(alpha, w[i]);   // :671
+    if (threadIdx.x == 0) out[0] = alpha;
+}
+
+// out = a + b (g_minor = H*s + g, src/basic_tralcnlss.jl:412,:437)
+__global__ __launch_bounds__(256) void vec_add_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[i] = __dadd_rn(a[i], b[i]);
 }
 
 // Stand-alone factor_to_boundary (tests).

@@ -330,6 +330,48 @@ def projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, atol=SQRT_EPS, atol_f2b=
     return w, st
 
 
+def linesearch(g_model, H, w, w_l, w_u, lincons):
+    """``linesearch(g_model, H, w, w_l, w_u, fix_bounds)`` — src/basic_tralcnlss.jl:766-791 (``fix_bounds`` = lincons.fixvars)."""
+    n = H.n
+    out = C.c_double(0.0)
+    g, w, wl, wu = as_f64(g_model, n), as_f64(w, n), as_f64(w_l, n), as_f64(w_u, n)
+    check(_lib.lib().bh_linesearch(H.handle, lincons.handle, ptr(g), ptr(w), ptr(wl), ptr(wu), C.byref(out)), "bh_linesearch")
+    return out.value
+
+
+def minor_iterate(x, s, g_model, H, lincons, delta, kappa2, atol=SQRT_EPS, atol_f2b=1e-10, full_output=False):
+    """``minor_iterate(x, s, g_model, H, lincons, delta, kappa2)`` — src/basic_tralcnlss.jl:649-675, one device-resident
+    call (step bounds, projected_cg, linesearch, scaling).  Returns ``(w, cg_status)`` like the reference."""
+    n = H.n
+    x, s, g = as_f64(x, n), as_f64(s, n), as_f64(g_model, n)
+    w = np.empty(n)
+    status, iters, n_hmul, alpha = C.c_int32(-1), C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+    check(_lib.lib().bh_minor_iterate(H.handle, lincons.handle, ptr(x), ptr(s), ptr(g), ptr(lincons.xlow), ptr(lincons.xupp),
+                                      float(delta), float(kappa2), float(atol), float(atol_f2b), ptr(w), C.byref(status),
+                                      C.byref(iters), C.byref(n_hmul), C.byref(alpha)), "bh_minor_iterate")
+    st = CGStatus(status.value)
+    if full_output:
+        return w, st, {"iters": iters.value, "n_hmul": n_hmul.value, "alpha": alpha.value}
+    return w, st
+
+
+def gradient(H, rx, y_bar=None):
+    """``g = Jx'*rx + Cx'*y_bar`` — src/basic_tralcnlss.jl:45,:74."""
+    r = as_f64(rx, H.d)
+    yb = np.zeros(H.q) if y_bar is None else as_f64(y_bar, H.q)
+    out = np.empty(H.n)
+    check(_lib.lib().bh_grad(H.handle, ptr(r), ptr(yb), ptr(out)), "bh_grad")
+    return out
+
+
+def hmul_add(H, s, g):
+    """``H*s + g`` — src/basic_tralcnlss.jl:412,:437."""
+    s, g = as_f64(s, H.n), as_f64(g, H.n)
+    out = np.empty(H.n)
+    check(_lib.lib().bh_hmul_add(H.handle, ptr(s), ptr(g), ptr(out)), "bh_hmul_add")
+    return out
+
+
 class DeviceVector:
     """A float64 vector resident in HBM (plumbing for the ``*_dev`` entry points)."""
 

@@ -160,6 +160,24 @@ int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const doub
                    double kappa2, double atol_negcurv, double atol_f2b,
                    double* w_out_dev, int32_t* status, int32_t* iters,
                    double* trace, int64_t trace_cap, int32_t* n_hmul);
+/* ---- callers of projected_cg, device-resident (SURVEY.md §8 a9, a10 and "next" row f-2) ----------------- */
+
+/* minor_iterate(x, s, g_model, H, lincons, delta, kappa2) — src/basic_tralcnlss.jl:649-675: builds w_l/w_u exactly as :660-665
+ * (only the FIXED variables get finite bounds), runs projected_cg (:667) and, unless the status is
+ * negative_curvature, linesearch and w .= alpha*w (:669-672) — one call, no intermediate PCIe round trips.
+ * xlow/xupp = lincons.xlow/xupp.  alpha_out (optional) receives the line-search factor (NaN when it was skipped). */
+int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* s, const double* g_model,
+                         const double* xlow, const double* xupp, double delta, double kappa2,
+                         double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters,
+                         int32_t* n_hmul, double* alpha_out);
+/* linesearch(g_model, H, w, w_l, w_u, lincons.fixvars) — src/basic_tralcnlss.jl:766-791. */
+int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const double* w, const double* w_l, const double* w_u,
+                      double* alpha_out);
+/* g = Jx'*rx + Cx'*y_bar — src/basic_tralcnlss.jl:45 (new_point), :74 (first_derivatives); r = this rank's d rows, y_bar has q entries. */
+int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out);
+/* g_minor = H*s + g — src/basic_tralcnlss.jl:412,:437. */
+int32_t bh_hmul_add(bh_hess* H, const double* s, const double* g, double* out_n);
+
 /* factor_to_boundary(p, w, w_l, w_u; atol) — src/basic_tralcnlss.jl:793-809, stand-alone (tests). */
 int32_t bh_factor_to_boundary(const double* p, const double* w, const double* w_l, const double* w_u,
                               int64_t n, double atol, double* gamma_out);

@@ -114,6 +114,21 @@ function BEnlsip.projected_cg(g_minor::Vector{Float64}, H::BEnlsip.AlHessian{Flo
     return w, (status[] == 4 ? nothing : BEnlsip.CG_status(status[]))
 end
 
+# minor_iterate(x, s, g_model, H, lincons, delta, kappa2) — src/basic_tralcnlss.jl:649-675 — one device-resident call:
+# step bounds (:660-665), projected_cg (:667), linesearch and scaling (:669-672); saves four PCIe round trips per minor iterate.
+function BEnlsip.minor_iterate(x::Vector{Float64}, s::Vector{Float64}, g_model::Vector{Float64}, H::BEnlsip.AlHessian{Float64},
+                               lincons::BEnlsip.MixedConstraints{Float64}, delta::Float64, kappa2::Float64)
+    n = length(x)
+    w = Vector{Float64}(undef, n)
+    status = Ref{Int32}(-1); iters = Ref{Int32}(0); nh = Ref{Int32}(0); alpha = Ref{Float64}(0.0)
+    check(ccall((:bh_minor_iterate, libbh), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Float64,
+                 Float64, Float64, Ptr{Float64}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Float64}),
+                handle(H), handle(lincons), x, s, g_model, lincons.xlow, lincons.xupp, delta, kappa2,
+                sqrt(eps(Float64)), 1e-10, w, status, iters, nh, alpha), "bh_minor_iterate")
+    return w, (status[] == 4 ? nothing : BEnlsip.CG_status(status[]))
+end
+
 # ---- multi-GPU: one Julia process per GPU (e.g. MPI.jl / Distributed); rows of J and of r are sharded by the caller ----
 unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bh_comm_unique_id, libbh), Int32, (Ptr{UInt8},), id), "bh_comm_unique_id"); id)
 comm_init(rank::Integer, nranks::Integer, id::Vector{UInt8}) =

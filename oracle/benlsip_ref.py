@@ -451,7 +451,8 @@ def inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa
     ops = ops or NumpyOps()
     m, n = lincons.lineq.shape
     s = cauchy_step(x, g, H, chol_aat_L, lincons, delta, ops)      # :410
-    g_minor = ops.hmul(H, s) + g                                   # :412
+    hmul_add = getattr(ops, "hmul_add", lambda H_, s_, g_: ops.hmul(H_, s_) + g_)
+    g_minor = hmul_add(H, s, g)                                    # :412
     j = 1
     norm_reduced_g = norm_reduced_gradient(g, lincons, ops)        # :420
     norm_reduced_g_minor = norm_reduced_gradient(g_minor, lincons, ops)
@@ -460,12 +461,15 @@ def inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa
     max_minor_step = min(nb_minor_step, allowed_minor_step)
     cg_stop = False
     while j <= max_minor_step and (not approx_solved) and (not cg_stop):  # :430
-        w, cg_status = minor_iterate(x, s, g_minor, H, lincons, delta, kappa2, ops)
+        if hasattr(ops, "minor_iterate"):      # backend provides the whole minor iterate (bh_minor_iterate)
+            w, cg_status = ops.minor_iterate(x, s, g_minor, H, lincons, delta, kappa2)
+        else:
+            w, cg_status = minor_iterate(x, s, g_minor, H, lincons, delta, kappa2, ops)
         if log is not None:
             log.append(("minor", int(cg_status)))
         cg_stop = cg_status == CGStatus.negative_curvature
         s = s + w                                                  # :436
-        g_minor = ops.hmul(H, s) + g                               # :437
+        g_minor = hmul_add(H, s, g)                                # :437
         active_indx = active_bounds(lincons, x, s, delta)          # :439
         if m + active_indx.shape[0] <= n:                          # :441
             add_active(lincons, chol_aat_L, active_indx)

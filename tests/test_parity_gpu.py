@@ -413,10 +413,24 @@ class HipOps:
         return w, R.CGStatus(int(status))
 
 
-def test_sphere_regression_through_c_abi(bh):
+class HipOpsDeviceMinor(HipOps):
+    """Same, with the whole minor iterate (step bounds + projected_cg + linesearch + scaling) and H*s+g on the device
+    (bh_minor_iterate, bh_hmul_add: SURVEY.md §8 a10 / f-2)."""
+
+    def minor_iterate(self, x, s, g_model, H, lincons, delta, kappa2):
+        self.n_pcg += 1
+        w, status = self.bh.minor_iterate(x, s, g_model, H, self._dev(lincons), delta, kappa2)
+        return w, R.CGStatus(int(status))
+
+    def hmul_add(self, H, s, g):
+        return self.bh.hmul_add(H, s, g)
+
+
+@pytest.mark.parametrize("ops_cls", [HipOps, HipOpsDeviceMinor], ids=["pcg_abi", "minor_iterate_abi"])
+def test_sphere_regression_through_c_abi(bh, ops_cls):
     """BASELINE config 1: test/problems/sphere_regression.jl with every hot-path call on the GPU; the three acceptance
     inequalities of :63-65 and agreement with the CPU oracle's solution."""
-    ops = HipOps(bh)
+    ops = ops_cls(bh)
     xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u,
                           max_outer_iter=100, max_inner_iter=250, ops=ops)
     assert ops.n_pcg > 10
@@ -488,3 +502,49 @@ def test_workspace_reuse_across_sizes_and_odd_n(bh):
         w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
         assert int(status) == int(s_ref) and info["iters"] == it_ref, (n, mA)
         assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), (n, mA)
+
+
+# ----------------------------------------------------------------------------- callers on the device (a9, a10, f-2)
+@pytest.mark.parametrize("d,n,q,mA,nfix,seed", [(60, 24, 1, 0, 5, 1), (200, 65, 0, 3, 9, 2), (1500, 700, 2, 8, 90, 3), (300, 128, 0, 0, 0, 4)])
+def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
+    """minor_iterate (:649-675), linesearch (:766-791), g = J'r + C'y_bar (:45), H*s+g (:412) against the oracle."""
+    rng = np.random.default_rng(seed)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, nfix, replace=False)] = True
+    xlow, xupp = -np.ones(n), np.ones(n)
+    cons_o = R.make_mixed_constraints(A, L0, fix if nfix else None, l=xlow, u=xupp)
+    x = np.clip(0.4 * rng.standard_normal(n), -0.9, 0.9)
+    x[fix] = np.where(rng.random(nfix) < 0.5, -1.0, 1.0)
+    s = 0.01 * rng.standard_normal(n)
+    s[fix] = 0.0
+    Ho = R.AlHessian(J, C, 10.0)
+    H = bh.AlHessian(J, C, 10.0)
+    cons = bh.MixedConstraints(A, cons_o.chol_L, fix, l=xlow, u=xupp)
+    rx, ybar = rng.standard_normal(d), rng.standard_normal(q)
+    g = J.T @ rx + C.T @ ybar
+    assert np.linalg.norm(bh.gradient(H, rx, ybar) - g) <= 1e-12 * np.linalg.norm(np.abs(J).T @ np.abs(rx) + np.abs(C).T @ np.abs(ybar))
+    gm_ref = R.hmul(Ho, s) + g
+    gm = bh.hmul_add(H, s, g)
+    assert relnorm(gm, gm_ref) <= 1e-12
+    delta = 0.1 * np.linalg.norm(g)
+    # linesearch on a fixed direction
+    w_l, w_u = R.build_step_bounds(x + s, cons_o, delta)
+    wdir = R.projection(cons_o, -gm_ref)
+    a_ref = R.linesearch(gm_ref, Ho, wdir, w_l, w_u, cons_o.fixvars)
+    a = bh.linesearch(gm_ref, H, wdir, w_l, w_u, cons)
+    assert a == pytest.approx(a_ref, rel=1e-12)
+    # the whole minor iterate
+    w_ref, st_ref = R.minor_iterate(x, s, gm_ref, Ho, cons_o, delta, 0.1)
+    w, st, info = bh.minor_iterate(x, s, gm_ref, H, cons, delta, 0.1, full_output=True)
+    assert int(st) == int(st_ref)
+    wl2, wu2 = R.build_step_bounds(x + s, cons_o, delta)
+    w_cg, s_cg, it_cg = R.projected_cg(gm_ref, Ho, wl2, wu2, cons_o, 0.1)
+    assert info["iters"] == it_cg
+    tol = w_tolerance(gm_ref, Ho, wl2, wu2, cons_o, 0.1, w_cg)
+    assert relnorm(w, w_ref) <= 10 * tol, (relnorm(w, w_ref), tol)
+    if int(st_ref) != int(R.CGStatus.negative_curvature):
+        assert info["alpha"] == pytest.approx(R.linesearch(gm_ref, Ho, w_cg, wl2, wu2, cons_o.fixvars), rel=1e-6)
