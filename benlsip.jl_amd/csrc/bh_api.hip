@@ -212,7 +212,8 @@ struct bh_proj {
     double* L = nullptr;           // mpp x mpp: the caller's augmented factor (reference form)
     int64_t L_cap = 0;
     bool have_L = false;
-    double* Lr = nullptr;          // mA x mA: chol(A_free A_free'), built on the device (reduced form)
+    double* M = nullptr;           // mA x mA: A_free A_free' (lower triangle), kept for rank-one downdates (bh_cauchy_step)
+    double* Lr = nullptr;          // mA x mA + mA: chol(M) and its reciprocal diagonal (reduced form)
     int* info = nullptr;           // device flag of chol_lower_kernel
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
     std::vector<uint64_t> last_chunks;   // fixvars of the last successful bh_proj_set_active (reduced form: skip identical pushes)
@@ -412,10 +413,30 @@ int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_dev
 }
 
 // ---- projection -------------------------------------------------------------------------
-ProjArgs proj_args(bh_proj* P, const CgState* st, bool reduced) {
+int32_t ensure_reduced_buffers(bh_proj* P) {
+    const int64_t mA = P->mA;
+    if (!P->M) BH_TRY(dev_alloc(&P->M, mA * mA));
+    if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, mA * mA + mA));
+    if (!P->info) BH_TRY(dev_alloc(&P->info, 1));
+    return BH_OK;
+}
+
+// M = A_free A_free' from the device-side mask, then Lr = chol(M).  `gate`: skip when gate->done (in-loop use).
+int32_t launch_reduced_factor(bh_proj* P, bool use_mask, const CgState* gate) {
+    const int mA = (int)P->mA;
+    const int64_t pairs = (int64_t)mA * (mA + 1) / 2;
+    hipLaunchKernelGGL(gram_free_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
+                       use_mask ? P->fixrank : (const int*)nullptr, P->M);
+    if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
+    else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+ProjArgs proj_args(bh_proj* P, const CgState* st, bool reduced, bool force_mask = false) {
     ProjArgs a{};
     a.A = P->Ad; a.ldA = P->ldA; a.mA = (int)P->mA; a.n = (int)P->n; a.nfix = P->nfix;
-    a.fixrank = P->nfix > 0 ? P->fixrank : nullptr;
+    a.fixrank = (P->nfix > 0 || force_mask) ? P->fixrank : nullptr;
     a.fixidx = P->fixidx; a.tw = P->tw; a.state = st;
     a.reduced = reduced ? 1 : 0;
     a.L = reduced ? P->Lr : P->L;
@@ -436,16 +457,17 @@ void launch_cg_step(const CgArgs& a, hipStream_t s) {
 size_t trsv_lds_bytes(int m) { return ((size_t)((m + 1) & ~1) + 64 * 65) * sizeof(double); }
 
 // v_out = P(r_pad): r_pad is a zero-padded ldA-length device vector, v_out has >= n entries.
-int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgState* st) {
+int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgState* st, bool device_mask = false) {
+    // device_mask: the active set lives in P->fixrank on the device and may be ahead of the host's P->nfix (bh_cauchy_step)
     const int n = (int)P->n;
     if (P->mA == 0) {
         const int grid = std::max(1, std::min((n + 255) / 256, 1024));
         hipLaunchKernelGGL(proj_mask_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, r_pad, v_out,
-                           P->nfix > 0 ? P->fixrank : (const int*)nullptr, n, st);
+                           (P->nfix > 0 || device_mask) ? P->fixrank : (const int*)nullptr, n, st);
         BH_HIP(hipGetLastError());
         return BH_OK;
     }
-    ProjArgs a = proj_args(P, st, P->reduced);
+    ProjArgs a = proj_args(P, st, device_mask ? true : P->reduced, device_mask);
     const int grid1 = a.mA + (a.reduced ? 0 : (a.nfix + 255) / 256);
     hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, r_pad);
     if (a.reduced && a.mpp <= 64) hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, a);
@@ -830,13 +852,8 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     if (reduced) {
         // reduced form: factor A_free A_free' (mA x mA) on the device; bound changes need no host factor
         const int mA = (int)P->mA;
-        if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, (int64_t)mA * mA + mA));
-        if (!P->info) BH_TRY(dev_alloc(&P->info, 1));
-        const int64_t pairs = (int64_t)mA * (mA + 1) / 2;
-        hipLaunchKernelGGL(gram_free_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
-                           nfix > 0 ? P->fixrank : (const int*)nullptr, P->Lr);
-        if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, P->Lr, mA, P->info);
-        else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->Lr, mA, P->info);
+        BH_TRY(ensure_reduced_buffers(P));
+        BH_TRY(launch_reduced_factor(P, nfix > 0, nullptr));
         BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
     }
     BH_HIP(hipStreamSynchronize(g_ctx.stream));   // host vectors go out of scope
@@ -858,7 +875,7 @@ int32_t bh_proj_destroy(bh_proj* P) {
     if (!P) return BH_OK;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
-    dev_free(P->Lr); dev_free(P->info);
+    dev_free(P->Lr); dev_free(P->M); dev_free(P->info);
     delete P;
     return BH_OK;
 }
@@ -1165,6 +1182,114 @@ int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* ou
     BH_TRY(fetch_vec(out_n, H->zpad, n, false));
     BH_HIP(hipStreamSynchronize(g_ctx.stream));
     H->stats.n_hmul += 1;
+    return BH_OK;
+}
+
+// Shared by bh_proj_set_active and bh_cauchy_step: make the host bookkeeping and the canonical device arrays
+// (fixrank = rank among fixed, fixidx) match `mask` (n entries, nonzero = fixed).
+static int32_t adopt_mask(bh_proj* P, const std::vector<int>& rank, const std::vector<int>& idx) {
+    BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+    if (!idx.empty()) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    return BH_OK;
+}
+
+// cauchy_step(x, g, H, chol_aat, lincons, delta) — src/basic_tralcnlss.jl:574-639, device-resident: initial
+// active_bounds! (poly:203-215), projection of -g, then per breakpoint one H*d, one projection and — instead of the
+// reference's O(p^3) host refactorisation (add_active! -> cholesky_aug_aat) — a rank-one downdate of A_free A_free' and an
+// mA x mA Cholesky on the device.  On return lincons' active set is the one the reference would hold (fix_chunks_out).
+int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g, const double* xlow, const double* xupp, double delta,
+                       double* s_out, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul_out) {
+    BH_REQUIRE_INIT();
+    if (!H || !P) return fail(BH_ERR_INVALID_ARG, "NULL handle");
+    if (!x || !g || !xlow || !xupp || !s_out) return fail(BH_ERR_INVALID_ARG, "NULL vector argument");
+    if (H->n != P->n) return fail(BH_ERR_SHAPE, "H.n != lincons.n");
+    if (P->mA > 0 && g_ctx.opt_proj_form == 0)
+        return fail(BH_ERR_UNSUPPORTED, "bh_cauchy_step needs the reduced projection form (proj_form = 1)");
+    const int64_t n = H->n;
+    const int mA = (int)P->mA;
+    BH_TRY(ensure_cg_workspace(H->ld, 0));
+    CgWorkspace& c = g_ctx.cg;
+    hipStream_t s = g_ctx.stream;
+    if (mA > 0) {
+        BH_TRY(ensure_reduced_buffers(P));
+        const size_t lds = trsv_lds_bytes(mA);
+        if (lds > 160 * 1024) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
+        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    BH_TRY(stage_vec(c.x, x, n, false));
+    BH_TRY(stage_vec(c.g, g, n, false));
+    BH_TRY(stage_vec(c.xlow, xlow, n, false));
+    BH_TRY(stage_vec(c.xupp, xupp, n, false));
+
+    CauchyArgs a{};
+    a.st = c.d_state; a.x = c.x; a.g = c.g; a.xlow = c.xlow; a.xupp = c.xupp;
+    a.negg = c.r; a.d = c.p; a.Hd = c.Hp; a.s = c.w; a.dl = c.wl; a.du = c.wu;
+    a.fixrank = P->fixrank; a.n = (int)n; a.n_pad = (int)H->ld; a.nmm = (int)(n - mA);
+    a.delta = delta; a.atol = std::sqrt(2.220446049250313e-16);
+    c.tag = (c.tag + 1) & 0xffffu;
+    if (c.tag == 0) c.tag = 1;
+    a.mirror = c.d_mirror; a.tag = c.tag;
+
+    P->active_set = false;             // device mask is authoritative until adopt_mask below
+    hipLaunchKernelGGL(cauchy_init_kernel, dim3(1), dim3(CG_T), 0, s, a);
+    if (mA > 0) BH_TRY(launch_reduced_factor(P, true, nullptr));
+    const int max_pass = (int)std::min<int64_t>(n + 1, 0xfffff);
+    int launched = 0;
+    auto launch_pass = [&](int index) -> int32_t {
+        if (index > 0 && mA > 0) {
+            hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
+                               (const CgState*)c.d_state);
+            if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+            else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+        }
+        BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632
+        BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, -1));           // Hd = H*d    :609 / :633
+        hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CG_T), 0, s, a);
+        BH_HIP(hipGetLastError());
+        return BH_OK;
+    };
+    MirrorWord mw{};
+    const int batch = (int)g_ctx.opt_batch;
+    auto launch_batch = [&](int nb) -> int32_t {
+        nb = std::min(nb, max_pass - launched);
+        for (int i = 0; i < nb; ++i) BH_TRY(launch_pass(launched + i));
+        launched += nb;
+        return BH_OK;
+    };
+    BH_TRY(launch_batch(2));
+    BH_TRY(wait_mirror(c, a.tag, launched, &mw));       // mirror: status field = error flag, iter field = breakpoints
+    while (!mw.done && launched < max_pass) {
+        const int target = launched;
+        (void)target;
+        BH_TRY(launch_batch(batch));
+        BH_TRY(wait_mirror(c, a.tag, launched, &mw));
+    }
+    std::vector<int> mask((size_t)P->ldA, -1);
+    BH_TRY(fetch_vec(s_out, c.w, n, false));
+    BH_HIP(hipMemcpyAsync(mask.data(), P->fixrank, (size_t)P->ldA * sizeof(int), hipMemcpyDeviceToHost, s));
+    int info_host = 0;
+    if (mA > 0) BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    BH_HIP(hipStreamSynchronize(s));
+    H->stats.n_hmul += mw.n_hmul;
+    if (!mw.done) return fail(BH_ERR_HIP, "internal: Cauchy loop did not terminate");
+    // canonical bookkeeping for the final active set
+    std::vector<int> rank((size_t)P->ldA, -1), idx;
+    const size_t nwords = (size_t)((n + 63) / 64);
+    std::vector<uint64_t> chunks(nwords, 0ull);
+    for (int64_t i = 0; i < n; ++i)
+        if (mask[(size_t)i] >= 0) { rank[(size_t)i] = (int)idx.size(); idx.push_back((int)i); chunks[(size_t)(i >> 6)] |= 1ull << (i & 63); }
+    BH_TRY(adopt_mask(P, rank, idx));
+    P->nfix = (int)idx.size(); P->mpp = mA + P->nfix; P->reduced = mA > 0; P->have_L = false;
+    P->last_chunks = chunks;
+    P->active_set = true;
+    if (fix_chunks_out) memcpy(fix_chunks_out, chunks.data(), nwords * sizeof(uint64_t));
+    if (n_breakpoints) *n_breakpoints = mw.iter;
+    if (n_hmul_out) *n_hmul_out = mw.n_hmul;
+    if (mw.status != 0)
+        return fail(BH_ERR_PRECONDITION, "cauchy_step: no breakpoint left (the reference indexes fixvars[-1] here, src/basic_tralcnlss.jl:631)");
+    if (info_host != 0)
+        return fail(BH_ERR_PRECONDITION, "cauchy_step: A_free*A_free' lost positive definiteness (PosDefException in the reference)");
     return BH_OK;
 }
 

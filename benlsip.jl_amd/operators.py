@@ -355,6 +355,28 @@ def minor_iterate(x, s, g_model, H, lincons, delta, kappa2, atol=SQRT_EPS, atol_
     return w, st
 
 
+def cauchy_step(x, g, H, lincons, delta, full_output=False):
+    """``cauchy_step(x, g, H, chol_aat, lincons, delta)`` — src/basic_tralcnlss.jl:574-639, device-resident.  Returns the
+    Cauchy step ``s_c``; like the reference it leaves ``lincons.fixvars`` at the active set found along the projected
+    gradient path (``lincons.chol`` is NOT rebuilt: the device keeps its own reduced factor)."""
+    n = H.n
+    x, g = as_f64(x, n), as_f64(g, n)
+    s = np.empty(n)
+    nwords = (n + 63) // 64
+    chunks = np.zeros(nwords, dtype=np.uint64)
+    nbp, nh = C.c_int32(0), C.c_int32(0)
+    lincons._sync()
+    check(_lib.lib().bh_cauchy_step(H.handle, lincons._h, ptr(x), ptr(g), ptr(lincons.xlow), ptr(lincons.xupp), float(delta), ptr(s),
+                                    ptr(chunks), C.byref(nbp), C.byref(nh)), "bh_cauchy_step")
+    bits = np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].astype(bool)
+    lincons._fixvars = bits
+    lincons._chol = None
+    lincons._dirty = False          # the device already holds this active set
+    if full_output:
+        return s, {"n_breakpoints": nbp.value, "n_hmul": nh.value}
+    return s
+
+
 def gradient(H, rx, y_bar=None):
     """``g = Jx'*rx + Cx'*y_bar`` — src/basic_tralcnlss.jl:45,:74."""
     r = as_f64(rx, H.d)

@@ -173,6 +173,14 @@ int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* 
 /* linesearch(g_model, H, w, w_l, w_u, lincons.fixvars) — src/basic_tralcnlss.jl:766-791. */
 int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const double* w, const double* w_l, const double* w_u,
                       double* alpha_out);
+/* cauchy_step(x, g, H, chol_aat, lincons, delta) — src/basic_tralcnlss.jl:574-639 (with next_breakpoint :536-562 and the
+ * initial active_bounds!, src/polyhedral_constraints.jl:203-215), device-resident ("next" row f-3).  Per breakpoint: one
+ * H*d, one projection, and a rank-one downdate + mA x mA Cholesky on the device in place of the reference's O(p^3)
+ * add_active! -> cholesky_aug_aat rebuild.  Needs the reduced projection form (default).  On return the handle holds the
+ * final active set; fix_chunks_out (ceil(n/64) words, optional) receives it in BitVector.chunks layout so the caller can
+ * update lincons.fixvars (and its own factor, if it still needs one). */
+int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g, const double* xlow, const double* xupp,
+                       double delta, double* s_out, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul);
 /* g = Jx'*rx + Cx'*y_bar — src/basic_tralcnlss.jl:45 (new_point), :74 (first_derivatives); r = this rank's d rows, y_bar has q entries. */
 int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out);
 /* g_minor = H*s + g — src/basic_tralcnlss.jl:412,:437. */

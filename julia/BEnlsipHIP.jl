@@ -129,6 +129,25 @@ function BEnlsip.minor_iterate(x::Vector{Float64}, s::Vector{Float64}, g_model::
     return w, (status[] == 4 ? nothing : BEnlsip.CG_status(status[]))
 end
 
+# cauchy_step(x, g, H, chol_aat, lincons, delta) — src/basic_tralcnlss.jl:574-639 — device-resident breakpoint search.  The
+# library leaves its own active set at the final one; lincons is brought to the state the reference's method leaves
+# behind (fixvars + one refreshed factor instead of one O(p^3) rebuild per breakpoint).
+function BEnlsip.cauchy_step(x::Vector{Float64}, g::Vector{Float64}, H::BEnlsip.AlHessian{Float64},
+                             chol_aat::Cholesky{Float64,Matrix{Float64}}, lincons::BEnlsip.MixedConstraints{Float64},
+                             delta::Float64)
+    n = length(x)
+    s_c = Vector{Float64}(undef, n)
+    chunks = zeros(UInt64, length(lincons.fixvars.chunks))
+    nbp = Ref{Int32}(0); nh = Ref{Int32}(0)
+    check(ccall((:bh_cauchy_step, libbh), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64},
+                 Ptr{UInt64}, Ref{Int32}, Ref{Int32}),
+                handle(H), handle(lincons), x, g, lincons.xlow, lincons.xupp, delta, s_c, chunks, nbp, nh), "bh_cauchy_step")
+    lincons.fixvars.chunks .= chunks
+    BEnlsip.update_chol!(lincons, chol_aat)
+    return s_c
+end
+
 # ---- multi-GPU: one Julia process per GPU (e.g. MPI.jl / Distributed); rows of J and of r are sharded by the caller ----
 unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bh_comm_unique_id, libbh), Int32, (Ptr{UInt8},), id), "bh_comm_unique_id"); id)
 comm_init(rank::Integer, nranks::Integer, id::Vector{UInt8}) =

@@ -450,7 +450,10 @@ def inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa
     """src/basic_tralcnlss.jl:394-460."""
     ops = ops or NumpyOps()
     m, n = lincons.lineq.shape
-    s = cauchy_step(x, g, H, chol_aat_L, lincons, delta, ops)      # :410
+    if hasattr(ops, "cauchy_step"):         # backend provides the whole Cauchy search (bh_cauchy_step); it must leave
+        s = ops.cauchy_step(x, g, H, chol_aat_L, lincons, delta)   # lincons.fixvars / chol_L as the reference would
+    else:
+        s = cauchy_step(x, g, H, chol_aat_L, lincons, delta, ops)  # :410
     hmul_add = getattr(ops, "hmul_add", lambda H_, s_, g_: ops.hmul(H_, s_) + g_)
     g_minor = hmul_add(H, s, g)                                    # :412
     j = 1

@@ -426,7 +426,19 @@ class HipOpsDeviceMinor(HipOps):
         return self.bh.hmul_add(H, s, g)
 
 
-@pytest.mark.parametrize("ops_cls", [HipOps, HipOpsDeviceMinor], ids=["pcg_abi", "minor_iterate_abi"])
+class HipOpsDeviceAll(HipOpsDeviceMinor):
+    """Same, plus the Cauchy search on the device (bh_cauchy_step); the oracle-side lincons is brought
+    to the state the reference's cauchy_step leaves behind (fixvars + refreshed factor)."""
+
+    def cauchy_step(self, x, g, H, chol_aat_L, lincons, delta):
+        dev = self._dev(lincons)
+        s = self.bh.cauchy_step(x, g, H, dev, delta)
+        lincons.fixvars = dev.fixvars.copy()
+        R.update_chol(lincons, chol_aat_L)
+        return s
+
+
+@pytest.mark.parametrize("ops_cls", [HipOps, HipOpsDeviceMinor, HipOpsDeviceAll], ids=["pcg_abi", "minor_iterate_abi", "cauchy_abi"])
 def test_sphere_regression_through_c_abi(bh, ops_cls):
     """BASELINE config 1: test/problems/sphere_regression.jl with every hot-path call on the GPU; the three acceptance
     inequalities of :63-65 and agreement with the CPU oracle's solution."""
@@ -548,3 +560,44 @@ def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
     assert relnorm(w, w_ref) <= 10 * tol, (relnorm(w, w_ref), tol)
     if int(st_ref) != int(R.CGStatus.negative_curvature):
         assert info["alpha"] == pytest.approx(R.linesearch(gm_ref, Ho, w_cg, wl2, wu2, cons_o.fixvars), rel=1e-6)
+
+
+# ----------------------------------------------------------------------------- Cauchy step on the device (f-3)
+@pytest.mark.parametrize("d,n,mA,nact,delta_scale,seed", [(80, 30, 0, 4, 0.5, 1), (300, 120, 3, 10, 1.0, 2), (500, 200, 0, 0, 5.0, 3),
+                                                          (400, 96, 8, 6, 0.2, 4), (2000, 512, 4, 40, 2.0, 5), (60, 17, 1, 2, 1.0, 6)])
+def test_cauchy_step_parity(bh, d, n, mA, nact, delta_scale, seed):
+    """cauchy_step (src/basic_tralcnlss.jl:574-639) incl. next_breakpoint and the active-set growth, against the oracle:
+    same breakpoints, same final active set, same step."""
+    rng = np.random.default_rng(seed)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    xlow, xupp = -np.ones(n), np.ones(n)
+    x = np.clip(0.5 * rng.standard_normal(n), -0.95, 0.95)
+    act = rng.choice(n, nact, replace=False)
+    x[act] = np.where(rng.random(nact) < 0.5, -1.0, 1.0)
+    g = rng.standard_normal(n)
+    delta = delta_scale * 0.1 * np.linalg.norm(g)
+    Ho = R.AlHessian(J, np.zeros((0, n)), 10.0)
+    cons_o = R.make_mixed_constraints(A, L0, l=xlow, u=xupp)
+    n_hmul_ref = [0]
+
+    class Ops(R.NumpyOps):
+        def hmul(self, H, v):
+            n_hmul_ref[0] += 1
+            return R.hmul(H, v)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, Ops())
+    H = bh.AlHessian(J, None, 10.0)
+    cons = bh.MixedConstraints(A, L0, l=xlow, u=xupp)
+    s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+    assert np.array_equal(cons.fixvars, cons_o.fixvars), (np.flatnonzero(cons.fixvars), np.flatnonzero(cons_o.fixvars))
+    assert info["n_hmul"] == n_hmul_ref[0]
+    assert info["n_breakpoints"] == n_hmul_ref[0] - 1 or info["n_breakpoints"] == R.nb_fix(cons_o) - nact
+    assert np.linalg.norm(s - s_ref) <= 1e-9 * max(np.linalg.norm(s_ref), 1e-300), relnorm(s, s_ref)
+    # the step stays inside the trust region / bounds box and in null(A)
+    assert np.all(x + s <= xupp + 1e-12) and np.all(x + s >= xlow - 1e-12) and np.max(np.abs(s)) <= delta * (1 + 1e-12)
+    if mA:
+        assert np.linalg.norm(A @ s) <= 1e-10 * np.linalg.norm(A) * max(np.linalg.norm(s), 1e-300)
+    # the handle now holds the final active set: a projection agrees with the oracle's
+    r = rng.standard_normal(n)
+    assert np.linalg.norm(bh.projection(cons, r) - R.projection(cons_o, r)) <= 1e-10 * np.linalg.norm(r)
