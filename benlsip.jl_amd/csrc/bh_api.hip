@@ -427,7 +427,7 @@ int32_t launch_reduced_factor(bh_proj* P, bool use_mask, const CgState* gate) {
     const int64_t pairs = (int64_t)mA * (mA + 1) / 2;
     hipLaunchKernelGGL(gram_free_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
                        use_mask ? P->fixrank : (const int*)nullptr, P->M);
-    if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
+    if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
     else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
     BH_HIP(hipGetLastError());
     return BH_OK;
@@ -470,7 +470,7 @@ int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgS
     ProjArgs a = proj_args(P, st, device_mask ? true : P->reduced, device_mask);
     const int grid1 = a.mA + (a.reduced ? 0 : (a.nfix + 255) / 256);
     hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, r_pad);
-    if (a.reduced && a.mpp <= 64) hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(64), 0, g_ctx.stream, a);
+    if (a.reduced && a.mpp <= 64) hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, g_ctx.stream, a);
     else hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), trsv_lds_bytes(a.mpp), g_ctx.stream, a);
     const int nch = (n + 1) / 2;
     hipLaunchKernelGGL((proj_left_mul_tr_kernel<true>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
@@ -1240,7 +1240,7 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
         if (index > 0 && mA > 0) {
             hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
                                (const CgState*)c.d_state);
-            if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(64), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+            if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
             else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
         }
         BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632

@@ -1134,77 +1134,104 @@ __global__ __launch_bounds__(CG_T) void chol_lower_kernel(const double* __restri
     }
 }
 
-// Reduced-form factor for mA <= 64: one wave, lane i owns row i of M in registers; right-looking Cholesky with
-// v_readlane broadcasts (no LDS, no barriers).  Writes L (lower, column-major m x m) and the reciprocal diagonal
-// dinv[m] right after the matrix (M + m*m), which turns the substitutions' divisions into multiplications.
-__global__ __launch_bounds__(64) void chol_small_kernel(const double* __restrict__ Msrc, double* __restrict__ M, int m, int* info,
-                                                        const CgState* gate) {
+// Reduced-form factor for mA <= 64: right-looking Cholesky on 256 threads.  lane = row, wave w owns the 16-column panel
+// [16w, 16w+16) of that row in REGISTERS (statically indexed: the column loop is unrolled per panel); each step the
+// owning wave publishes column j through a double-buffered 64-entry LDS vector (one barrier per step) and every wave
+// applies the rank-one update to its panel.  (History: fully unrolled one-wave register version 100 us, instruction-fetch
+// bound; one-wave LDS loops 66-170 us, latency bound.)  Writes L (lower, column-major m x m) and the reciprocal diagonal
+// dinv[m] right after the matrix (dst + m*m), which turns the substitutions' divisions into multiplications.
+__global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ Msrc, double* __restrict__ M, int m, int* info,
+                                                         const CgState* gate) {
     if (gate != nullptr && gate->done) return;
-    const int lane = threadIdx.x;
-    double a[64];
+    __shared__ double colbuf[2][64];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double a[16];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) a[k] = (lane < m && k <= lane && k < m) ? Msrc[lane + (int64_t)k * m] : 0.0;
-    int bad = 0;
+    for (int c = 0; c < 16; ++c) {
+        const int k = 16 * wave + c;
+        a[c] = (lane < m && k < m && k <= lane) ? Msrc[lane + (int64_t)k * m] : 0.0;
+    }
+    if (tid == 0) s_bad = 0;
     double dinv_mine = 0.0;
+    int buf = 0;
+    __syncthreads();
+    for (int p = 0; p < 4; ++p) {
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (j < m) {
-            const double ajj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[j]), j),
-                                                __builtin_amdgcn_readlane(__double2loint(a[j]), j));
-            if (!(ajj > 0.0) && bad == 0) bad = j + 1;
-            const double d = sqrt(ajj);
-            const double inv = 1.0 / d;
-            if (lane == j) { a[j] = d; dinv_mine = inv; }
-            else if (lane > j) a[j] = a[j] / d;
-#pragma unroll
-            for (int k = j + 1; k < 64; ++k) {
-                if (k < m) {
-                    const double lkj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[j]), k),
-                                                        __builtin_amdgcn_readlane(__double2loint(a[j]), k));
-                    if (lane >= k) a[k] = fma(-a[j], lkj, a[k]);
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * p + jj;
+            if (j < m) {                                    // uniform
+                if (wave == p) {
+                    const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[jj]), j),
+                                                        __builtin_amdgcn_readlane(__double2loint(a[jj]), j));
+                    // one reciprocal square root instead of sqrt + 64 divisions: the dependent fp64 chain per step is the cost
+                    const double rinv = rsqrt(piv);
+                    if (!(piv > 0.0) && lane == 0 && s_bad == 0) s_bad = j + 1;
+                    double lij = 0.0;
+                    if (lane == j) { lij = piv * rinv; dinv_mine = rinv; }
+                    else if (lane > j) lij = a[jj] * rinv;
+                    a[jj] = lij;
+                    colbuf[buf][lane] = lij;
                 }
+                __syncthreads();
+                const double lij = colbuf[buf][lane];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const int k = 16 * wave + c;
+                    if (k > j && k < m) {
+                        const double lkj = colbuf[buf][k];          // broadcast read
+                        if (lane >= k) a[c] = fma(-lij, lkj, a[c]);
+                    }
+                }
+                buf ^= 1;
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 64; ++k)
-        if (lane < m && k <= lane && k < m) M[lane + (int64_t)k * m] = a[k];
-    if (lane < m) M[(int64_t)m * m + lane] = dinv_mine;
-    if (lane == 0 && (bad != 0 || gate == nullptr)) info[0] = bad;   // gated (in-loop) calls only ever raise the flag
+    for (int c = 0; c < 16; ++c) {
+        const int k = 16 * wave + c;
+        if (lane < m && k < m && k <= lane) M[lane + (int64_t)k * m] = a[c];
+    }
+    if (lane < m && wave == (lane >> 4)) M[(int64_t)m * m + lane] = dinv_mine;
+    __syncthreads();
+    if (tid == 0 && (s_bad != 0 || gate == nullptr)) info[0] = s_bad;   // gated (in-loop) calls only ever raise the flag
 }
 
-// tw <- L' \ (L \ tw) for m <= 64 (reduced form): one wave, row i and column i of L in registers, reciprocal diagonal
-// from chol_small_kernel; 2 x 64 dependent steps of readlane + mul + fma.
-__global__ __launch_bounds__(64) void trsv_small_kernel(ProjArgs a) {
+// tw <- L' \ (L \ tw) for m <= 64 (reduced form).  256 threads stage L into an LDS tile (all loads in flight at once,
+// row stride 65: conflict-free both row- and column-wise); wave 0 then runs the 2 x m dependent steps
+// (readlane + LDS read + fma) with the reciprocal diagonal from chol_small_kernel.
+__global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
     if (proj_skip(a.state)) return;
-    const int lane = threadIdx.x, m = a.mpp;
+    __shared__ double t[64 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = a.mpp;
     const double* __restrict__ L = a.L;
-    const double* __restrict__ dinv = a.L + (int64_t)m * m;
-    double Lrow[64], Lcol[64];
+    double tmp[16];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        Lrow[k] = (lane < m && k < lane) ? L[lane + (int64_t)k * m] : 0.0;      // L[i][k], k < i
-        Lcol[k] = (lane < m && k > lane && k < m) ? L[k + (int64_t)lane * m] : 0.0;   // L[k][i], k > i
+    for (int c = 0; c < 16; ++c) {
+        const int k = 16 * wave + c;
+        tmp[c] = (lane < m && k < m && k <= lane) ? L[lane + (int64_t)k * m] : 0.0;
     }
-    const double di = (lane < m) ? dinv[lane] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[lane * 65 + 16 * wave + c] = tmp[c];
+    __syncthreads();
+    if (wave != 0) return;
+    const double di = (lane < m) ? L[(int64_t)m * m + lane] : 0.0;
     double xi = (lane < m) ? a.tw[lane] : 0.0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        if (j < m) {
-            if (lane == j) xi = xi * di;
-            const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
-                                               __builtin_amdgcn_readlane(__double2loint(xi), j));
-            if (lane > j) xi = fma(-Lrow[j], xj, xi);
-        }
+#pragma unroll 8
+    for (int j = 0; j < m; ++j) {                           // forward: L y = t
+        const double lij = t[lane * 65 + j];
+        if (lane == j) xi = xi * di;
+        const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
+                                           __builtin_amdgcn_readlane(__double2loint(xi), j));
+        if (lane > j) xi = fma(-lij, xj, xi);
     }
-#pragma unroll
-    for (int j = 63; j >= 0; --j) {
-        if (j < m) {
-            if (lane == j) xi = xi * di;
-            const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
-                                               __builtin_amdgcn_readlane(__double2loint(xi), j));
-            if (lane < j) xi = fma(-Lcol[j], xj, xi);
-        }
+#pragma unroll 8
+    for (int j = m - 1; j >= 0; --j) {                      // backward: L' w = y   (L[j][i] = t[j*65 + i], consecutive lanes)
+        const double lji = t[j * 65 + lane];
+        if (lane == j) xi = xi * di;
+        const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
+                                           __builtin_amdgcn_readlane(__double2loint(xi), j));
+        if (lane < j) xi = fma(-lji, xj, xi);
     }
     if (lane < m) a.tw[lane] = xi;
 }
