@@ -17,14 +17,14 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    stats = max(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
     line = os.path.join(src, "bench_line_under_trace.json")
     if os.path.exists(line):
         shutil.copy(line, os.path.join(dst, tag + "_bench_line_under_trace.json"))
     pmc = {}
     for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
         if not files:
             continue
         acc = collections.defaultdict(list)
