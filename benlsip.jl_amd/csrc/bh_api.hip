@@ -191,6 +191,7 @@ struct bh_hess {
     double* vpad = nullptr;        // ld
     double* zpad = nullptr;        // ld
     double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
+    double* tbuf = nullptr;        // d + q   (t = J v between the two passes of a column-panel H*p; NULL for n <= 8192)
     double* partials = nullptr;    // g_cap x ld
     double* sq_partials = nullptr; // g_cap
     double* scalar = nullptr;      // 2
@@ -287,15 +288,64 @@ int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H) {
     return BH_OK;
 }
 
-// z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
-int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0) {
-    const int cfg = pick_config(H->nchunks);
-    const int64_t nrows = H->d + H->q_eff;
-    const int grid = grid_for(cfg, nrows);
+// Column panels: a row wider than the register-resident kernels can hold (ld/2 > kMaxChunks) is swept in panels of
+// kPanelChunks 16-byte chunks, one launch per panel; H*p then costs two passes over J (J v accumulated over panels into
+// tbuf, then J' (W .* t) per panel) instead of the fused single pass.
+constexpr int kPanelChunks = 2048;
+constexpr int kPanelCfg = 4;          // <256,8,4>: handles any panel up to 2048 chunks, same grid for every panel
+
+bool multi_panel(const bh_hess* H) { return H->nchunks > kMaxChunks; }
+
+RowStreamArgs rs_args(bh_hess* H, int64_t nrows, const CgState* state) {
     RowStreamArgs a{};
     a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
-    a.v = v_pad; a.u = nullptr; a.t_out = nullptr; a.partials = H->partials; a.sq_partials = nullptr;
-    a.mu = H->mu; a.state = state; a.reverse = reverse;
+    a.mu = H->mu; a.state = state;
+    return a;
+}
+
+// t (nrows) = J[:, all panels] v
+int32_t launch_jv_panels(bh_hess* H, const double* v_pad, double* t, int64_t nrows, const CgState* state) {
+    const int grid = grid_for(kPanelCfg, nrows);
+    for (int c0 = 0, p = 0; c0 < H->nchunks; c0 += kPanelChunks, ++p) {
+        RowStreamArgs a = rs_args(H, nrows, state);
+        a.J = H->Jd + 2 * (int64_t)c0; a.v = v_pad + 2 * (int64_t)c0;
+        a.nchunks = std::min(kPanelChunks, H->nchunks - c0);
+        a.t_out = t; a.accumulate = p > 0 ? 1 : 0;
+        launch_row_stream(kPanelCfg, MODE_JV, a, grid, g_ctx.stream);
+    }
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+// z_out (ld) = J[:, all panels]' (u or W.*u), reduced over workgroups
+int32_t launch_jtv_panels(bh_hess* H, const double* u, double* z_out, int64_t nrows, bool weighted, const CgState* state) {
+    const int grid = grid_for(kPanelCfg, nrows);
+    for (int c0 = 0; c0 < H->nchunks; c0 += kPanelChunks) {
+        RowStreamArgs a = rs_args(H, nrows, state);
+        a.J = H->Jd + 2 * (int64_t)c0; a.partials = H->partials + 2 * (int64_t)c0;
+        a.nchunks = std::min(kPanelChunks, H->nchunks - c0);
+        a.u = u; a.weighted_u = weighted ? 1 : 0;
+        launch_row_stream(kPanelCfg, MODE_JTV, a, grid, g_ctx.stream);
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
+                       H->partials, H->ld, H->nchunks, grid, z_out, state);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
+// z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
+int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0) {
+    const int64_t nrows = H->d + H->q_eff;
+    if (multi_panel(H)) {
+        BH_TRY(launch_jv_panels(H, v_pad, H->tbuf, nrows, state));
+        BH_TRY(launch_jtv_panels(H, H->tbuf, z_out, nrows, true, state));
+        BH_TRY(allreduce_inplace(z_out, H->n, H));
+        return BH_OK;
+    }
+    const int cfg = pick_config(H->nchunks);
+    const int grid = grid_for(cfg, nrows);
+    RowStreamArgs a = rs_args(H, nrows, state);
+    a.v = v_pad; a.partials = H->partials; a.reverse = reverse;
     // BH_FLAG_PROFILE: hipEvents around every kEvStride-th H*p launch of this handle, counted ACROSS calls (an event pair
     // costs ~10 us of stream time; timing every launch would slow the loop it measures by 3 %).
     bool timed = false;
@@ -322,14 +372,20 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
 }
 
 int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_rows, double* sq_out_scalar) {
-    const int cfg = pick_config(H->nchunks);
     const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
+    if (multi_panel(H)) {
+        double* t = t_out ? t_out : H->tbuf;
+        BH_TRY(launch_jv_panels(H, v_pad, t, nrows, nullptr));
+        if (sq_out_scalar)
+            hipLaunchKernelGGL(weighted_sqsum_kernel, dim3(1), dim3(1024), 0, g_ctx.stream, (const double*)t, nrows, H->d, H->mu, sq_out_scalar);
+        BH_HIP(hipGetLastError());
+        return BH_OK;
+    }
+    const int cfg = pick_config(H->nchunks);
     const int grid = grid_for(cfg, nrows);
-    RowStreamArgs a{};
-    a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
-    a.v = v_pad; a.t_out = t_out; a.partials = nullptr;
+    RowStreamArgs a = rs_args(H, nrows, nullptr);
+    a.v = v_pad; a.t_out = t_out;
     a.sq_partials = sq_out_scalar ? H->sq_partials : nullptr;
-    a.mu = H->mu; a.state = nullptr;
     launch_row_stream(cfg, MODE_JV, a, grid, g_ctx.stream);
     if (sq_out_scalar) {
         hipLaunchKernelGGL(reduce_scalar_kernel, dim3(1), dim3(256), 0, g_ctx.stream, H->sq_partials, grid, sq_out_scalar);
@@ -339,13 +395,16 @@ int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_ro
 }
 
 int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out, bool with_c_rows = false) {
-    const int cfg = pick_config(H->nchunks);
     const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
+    if (multi_panel(H)) {
+        BH_TRY(launch_jtv_panels(H, u_dev, z_out, nrows, false, nullptr));
+        BH_TRY(allreduce_inplace(z_out, H->n, H));
+        return BH_OK;
+    }
+    const int cfg = pick_config(H->nchunks);
     const int grid = grid_for(cfg, nrows);
-    RowStreamArgs a{};
-    a.J = H->Jd; a.ld = H->ld; a.nrows = nrows; a.d_rows = H->d; a.nchunks = H->nchunks;
-    a.v = nullptr; a.u = u_dev; a.t_out = nullptr; a.partials = H->partials; a.sq_partials = nullptr;
-    a.mu = H->mu; a.state = nullptr;
+    RowStreamArgs a = rs_args(H, nrows, nullptr);
+    a.u = u_dev; a.partials = H->partials;
     launch_row_stream(cfg, MODE_JTV, a, grid, g_ctx.stream);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
                        H->partials, H->ld, H->nchunks, grid, z_out, (const CgState*)nullptr);
@@ -358,13 +417,12 @@ int32_t alloc_hess_common(bh_hess* H) {
     const int64_t rows = H->d + H->q;
     H->ld = round_up(std::max<int64_t>(H->n, 1), 16);
     H->nchunks = (int)(H->ld / 2);
-    if (H->nchunks > kMaxChunks)
-        return fail(BH_ERR_UNSUPPORTED, "n > 8192 is not supported by the register-resident row kernels yet");
     H->q_eff = (g_ctx.rank == 0) ? H->q : 0;   // C is replicated: only rank 0 contributes C'(mu C v)
     BH_TRY(dev_alloc(&H->Jd, std::max<int64_t>(rows, 1) * H->ld));
     BH_TRY(dev_alloc(&H->vpad, H->ld));
     BH_TRY(dev_alloc(&H->zpad, H->ld));
     BH_TRY(dev_alloc(&H->upad, std::max<int64_t>(rows, 1)));
+    if (multi_panel(H)) BH_TRY(dev_alloc(&H->tbuf, std::max<int64_t>(rows, 1)));
     BH_HIP(hipMemsetAsync(H->vpad, 0, H->ld * sizeof(double), g_ctx.stream));
     BH_HIP(hipMemsetAsync(H->zpad, 0, H->ld * sizeof(double), g_ctx.stream));
     // partial slabs: enough for the largest grid any variant may use
@@ -373,7 +431,7 @@ int32_t alloc_hess_common(bh_hess* H) {
     BH_TRY(dev_alloc(&H->partials, gmax * H->ld));
     BH_TRY(dev_alloc(&H->sq_partials, gmax));
     BH_TRY(dev_alloc(&H->scalar, 2));
-    H->stats.bytes_per_hmul = 8.0 * (double)(H->d + H->q_eff) * (double)H->n + 16.0 * (double)H->n;
+    H->stats.bytes_per_hmul = (multi_panel(H) ? 16.0 : 8.0) * (double)(H->d + H->q_eff) * (double)H->n + 16.0 * (double)H->n;
     return BH_OK;
 }
 
@@ -704,7 +762,7 @@ int32_t bh_hess_set_mu(bh_hess* H, double mu) {
 int32_t bh_hess_destroy(bh_hess* H) {
     if (!H) return BH_OK;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
-    dev_free(H->Jd); dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad);
+    dev_free(H->Jd); dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf);
     dev_free(H->partials); dev_free(H->sq_partials); dev_free(H->scalar);
     for (auto e : H->ev) if (e) (void)hipEventDestroy(e);
     delete H;
@@ -851,7 +909,6 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     int info_host = 0;
     if (reduced) {
         // reduced form: factor A_free A_free' (mA x mA) on the device; bound changes need no host factor
-        const int mA = (int)P->mA;
         BH_TRY(ensure_reduced_buffers(P));
         BH_TRY(launch_reduced_factor(P, nfix > 0, nullptr));
         BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
@@ -988,22 +1045,27 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         return BH_OK;
     };
     // Progress comes back through one host-mapped 8-byte word the kernels store to (no copy kernels, no events).
+    // Multi-rank lock-step: every rank must take the SAME launch decisions (each launched iteration contains an
+    // all-reduce), so a decision taken after waiting for `target` iterations may only use "the loop had exited by
+    // iteration `target`" — never a later state that a slower-polling rank happened to see (the word keeps advancing
+    // while launch-ahead batches run).  done_by(target) is that rank-independent predicate.
     MirrorWord mw{};
+    auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
     const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, 8) : std::min(batch, 2);
     BH_TRY(launch_batch(first));
     BH_TRY(wait_mirror(c, a.tag, launched, &mw));
-    if (!mw.done && launched < max_iter) {
-        int target = launched;
+    if (!done_by(launched) && launched < max_iter) {
         BH_TRY(launch_batch(batch));
         while (true) {
-            target = launched;                       // everything enqueued so far except the batch launched next
+            const int target = launched;             // everything enqueued so far except the batch launched next
             const bool more = launched < max_iter;
             if (more) BH_TRY(launch_batch(batch));
             BH_TRY(wait_mirror(c, a.tag, target, &mw));
-            if (mw.done || !more) break;
+            if (done_by(target) || !more) break;
         }
-        if (!mw.done) BH_TRY(wait_mirror(c, a.tag, launched, &mw));
     }
+    BH_TRY(wait_mirror(c, a.tag, launched, &mw));      // the final state (all enqueued iterations have run or were no-ops)
+    if (!mw.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
     fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
     return BH_OK;
 }
@@ -1350,6 +1412,7 @@ int32_t bh_stats_reset(bh_hess* H) {
 int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
     BH_REQUIRE_INIT();
     if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 2) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    if (multi_panel(H)) return fail(BH_ERR_UNSUPPORTED, "bh_time_kernel: single-panel handles only (n <= 8192)");
     hipEvent_t e0, e1;
     BH_HIP(hipEventCreate(&e0));
     BH_HIP(hipEventCreate(&e1));

@@ -125,6 +125,8 @@ struct RowStreamArgs {
     double mu;
     const CgState* state;   // NULL, or skip the launch when state->done
     int reverse;            // sweep the row groups last-to-first (ping-pong order keeps the tail of J in the Infinity Cache)
+    int accumulate;         // JV: t_out += (column panels of a wide J are swept one launch each)
+    int weighted_u;         // JTV: coefficient u[row] * (row < d_rows ? 1 : mu)  (second pass of the two-pass H*p)
 };
 
 // NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
@@ -216,11 +218,11 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 if (rv) {
                     const double wgt = (row < a.d_rows) ? 1.0 : a.mu;
                     sq_acc = fma(wgt * s[r], s[r], sq_acc);
-                    if (a.t_out != nullptr && tid == r) a.t_out[row] = s[r];
+                    if (a.t_out != nullptr && tid == r) a.t_out[row] = a.accumulate ? a.t_out[row] + s[r] : s[r];
                 }
             } else {
                 double coef;
-                if (MODE == MODE_JTV) coef = rv ? a.u[row] : 0.0;
+                if (MODE == MODE_JTV) coef = rv ? (a.weighted_u && row >= a.d_rows ? a.mu * a.u[row] : a.u[row]) : 0.0;
                 else coef = (row < a.d_rows) ? s[r] : a.mu * s[r];
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
@@ -303,6 +305,19 @@ __global__ __launch_bounds__(256) void reduce_scalar_kernel(const double* __rest
     double acc[1] = {0.0};
     for (int i = threadIdx.x; i < m; i += 256) acc[0] += x[i];
     block_reduce<256, 1>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+// sum_i w_i t_i^2 with w_i = 1 (i < d_rows) or mu: vthv for a J swept in column panels.  Single workgroup.
+__global__ __launch_bounds__(1024) void weighted_sqsum_kernel(const double* __restrict__ t, int64_t nrows, int64_t d_rows, double mu,
+                                                               double* __restrict__ out) {
+    __shared__ double scratch[1024 / 64];
+    double acc[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < nrows; i += 1024) {
+        const double ti = t[i];
+        acc[0] = fma((i < d_rows) ? ti : mu * ti, ti, acc[0]);
+    }
+    block_reduce<1024, 1>(acc, scratch, OpSum(), 0.0);
     if (threadIdx.x == 0) out[0] = acc[0];
 }
 

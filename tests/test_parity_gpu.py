@@ -601,3 +601,31 @@ def test_cauchy_step_parity(bh, d, n, mA, nact, delta_scale, seed):
     # the handle now holds the final active set: a projection agrees with the oracle's
     r = rng.standard_normal(n)
     assert np.linalg.norm(bh.projection(cons, r) - R.projection(cons_o, r)) <= 1e-10 * np.linalg.norm(r)
+
+
+# ----------------------------------------------------------------------------- wide J (column panels, n > 8192)
+@pytest.mark.parametrize("d,n,q", [(70, 8200, 1), (40, 10001, 0), (33, 20000, 2)])
+def test_wide_jacobian_column_panels(bh, d, n, q):
+    """n > 8192: rows no longer fit one workgroup's registers; J is swept in 4096-column panels (two-pass H*p)."""
+    rng = np.random.default_rng(n)
+    J, C, mu = rng.standard_normal((d, n)), rng.standard_normal((q, n)), 0.5
+    v, u = rng.standard_normal(n), rng.standard_normal(d)
+    H, Ho = bh.AlHessian(J, C, mu), R.AlHessian(J, C, mu)
+    assert np.linalg.norm(H.jv(v) - J @ v) <= TOL1 * matvec_scale(J, v)
+    assert np.linalg.norm(H.jtv(u) - J.T @ u) <= TOL1 * matvec_scale(J.T, u)
+    scale = np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(v)) + mu * np.abs(C).T @ (np.abs(C) @ np.abs(v)))
+    assert np.linalg.norm(H * v - R.hmul(Ho, v)) <= TOL1 * scale
+    assert bh.vthv(H, v) == pytest.approx(R.vthv(Ho, v), rel=1e-12)
+    # a box-constrained CG on it (generic n-vector kernels); all but ~n/1000 (< d) variables fixed so that the rank-deficient
+    # H (d << n) restricted to the free variables is positive definite and the oracle needs few iterations
+    fix = np.ones(n, dtype=bool)
+    fix[::1000] = False
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix, l=-np.ones(n), u=np.ones(n))
+    g = rng.standard_normal(n)
+    w_l, w_u = R.build_step_bounds(np.where(fix, 1.0, 0.0), cons_o, 0.5)
+    w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+    cons = bh.MixedConstraints(A, None, fix)
+    w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
+    assert int(status) == int(s_ref) and info["iters"] == it_ref
+    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
