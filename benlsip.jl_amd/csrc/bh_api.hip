@@ -65,8 +65,11 @@ struct Ctx {
 
 Ctx g_ctx;
 
+void pin_arena_abandon();   // drops results parked for a call that is about to fail
+
 int32_t fail(int32_t code, const std::string& what) {
     g_ctx.detail = what;
+    pin_arena_abandon();
     return code;
 }
 
@@ -456,8 +459,45 @@ int32_t upload_transposed(const double* host, int64_t rows, int64_t cols, int64_
     return BH_OK;
 }
 
+// Host <-> device vector traffic goes through a pinned arena: the caller's arrays are pageable (Julia / NumPy heap), and a
+// pageable hipMemcpyAsync costs 20-25 us per 32 KiB vector; memcpy into pinned memory + a truly asynchronous DMA costs ~4.
+// The arena is a bump allocator reset by sync_flush(), which every export calls before returning (host pointers are only
+// borrowed for the duration of the call); results are copied out of the arena after the stream has drained.
+struct PendingOut { double* dst; const double* pin; int64_t n; };
+struct PinArena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<PendingOut> outs;
+};
+PinArena g_pin;
+void pin_arena_abandon() { g_pin.outs.clear(); g_pin.used = 0; }
+constexpr size_t kPinArenaBytes = 32u << 20;
+constexpr int64_t kPinMaxVec = 1 << 20;     // doubles; larger transfers go directly (bandwidth-, not latency-bound)
+
+double* pin_alloc(int64_t n) {
+    if (n > kPinMaxVec) return nullptr;
+    if (!g_pin.base) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, kPinArenaBytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+        g_pin.base = static_cast<char*>(p);
+        g_pin.cap = kPinArenaBytes;
+    }
+    const size_t bytes = ((size_t)n * sizeof(double) + 255) & ~(size_t)255;
+    if (g_pin.used + bytes > g_pin.cap) return nullptr;
+    double* r = reinterpret_cast<double*>(g_pin.base + g_pin.used);
+    g_pin.used += bytes;
+    return r;
+}
+
 int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_device) {
     if (n == 0) return BH_OK;
+    if (!src_is_device) {
+        if (double* pin = pin_alloc(n)) {
+            memcpy(pin, src, (size_t)n * sizeof(double));
+            BH_HIP(hipMemcpyAsync(dst_pad, pin, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
+            return BH_OK;
+        }
+    }
     BH_HIP(hipMemcpyAsync(dst_pad, src, (size_t)n * sizeof(double), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           g_ctx.stream));
     return BH_OK;
@@ -465,8 +505,26 @@ int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_dev
 
 int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_device) {
     if (n == 0) return BH_OK;
+    if (!dst_is_device) {
+        if (double* pin = pin_alloc(n)) {
+            BH_HIP(hipMemcpyAsync(pin, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
+            g_pin.outs.push_back({dst, pin, n});
+            return BH_OK;
+        }
+    }
     BH_HIP(hipMemcpyAsync(dst, src_dev, (size_t)n * sizeof(double), dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                           g_ctx.stream));
+    return BH_OK;
+}
+
+// hipStreamSynchronize + deliver the results parked in the pinned arena + reset the arena.
+int32_t sync_flush() {
+    hipError_t e = hipStreamSynchronize(g_ctx.stream);
+    if (e == hipSuccess)
+        for (const PendingOut& o : g_pin.outs) memcpy(o.dst, o.pin, (size_t)o.n * sizeof(double));
+    g_pin.outs.clear();
+    g_pin.used = 0;
+    if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
     return BH_OK;
 }
 
@@ -610,14 +668,14 @@ int32_t bh_shutdown(void) {
 
 int32_t bh_set_stream(void* hip_stream) {
     BH_REQUIRE_INIT();
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     g_ctx.stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : g_ctx.own_stream;
     return BH_OK;
 }
 
 int32_t bh_synchronize(void) {
     BH_REQUIRE_INIT();
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -722,7 +780,7 @@ int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int
     if (rc == BH_OK) rc = upload_transposed(J, d, n, ldJ, H->Jd, 0, H->ld);
     if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     *out = H;
     return BH_OK;
 }
@@ -783,7 +841,7 @@ static int32_t hmul_impl(bh_hess* H, const double* v, double* out, bool dev) {
     BH_TRY(stage_vec(H->vpad, v, H->n, dev));
     BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
     BH_TRY(fetch_vec(out, H->zpad, H->n, dev));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     H->stats.n_hmul += 1;
     return BH_OK;
 }
@@ -797,7 +855,7 @@ int32_t bh_vthv(bh_hess* H, const double* v, double* out_scalar) {
     BH_TRY(launch_jv(H, H->vpad, nullptr, true, H->scalar));
     BH_TRY(allreduce_inplace(H->scalar, 1, H));
     BH_TRY(fetch_vec(out_scalar, H->scalar, 1, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     H->stats.n_jv += 1;
     return BH_OK;
 }
@@ -812,7 +870,7 @@ static int32_t jv_impl(bh_hess* H, const double* v, double* out, bool dev) {
         BH_TRY(launch_jv(H, H->vpad, H->upad, false, nullptr));
         BH_TRY(fetch_vec(out, H->upad, H->d, false));
     }
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     H->stats.n_jv += 1;
     return BH_OK;
 }
@@ -826,7 +884,7 @@ static int32_t jtv_impl(bh_hess* H, const double* u, double* out, bool dev) {
     if (!dev) { BH_TRY(stage_vec(H->upad, u, H->d, false)); u_dev = H->upad; }
     BH_TRY(launch_jtv(H, u_dev, H->zpad));
     BH_TRY(fetch_vec(out, H->zpad, H->n, dev));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     H->stats.n_jtv += 1;
     return BH_OK;
 }
@@ -854,7 +912,7 @@ int32_t bh_proj_create(bh_proj** out, const double* A, int64_t mA, int64_t n, in
     if (rc == BH_OK) rc = upload_transposed(A, mA, n, ldA, P->Ad, 0, P->ldA);
     if (rc != BH_OK) { bh_proj_destroy(P); return rc; }
     P->nfix = 0; P->mpp = (int)mA;
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     *out = P;
     return BH_OK;
 }
@@ -913,7 +971,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
         BH_TRY(launch_reduced_factor(P, nfix > 0, nullptr));
         BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
     }
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));   // host vectors go out of scope
+    BH_TRY(sync_flush());   // host vectors go out of scope
     if (info_host != 0) {
         P->active_set = false;
         return fail(BH_ERR_PRECONDITION, "A_free*A_free' is not positive definite (PosDefException in the reference's cholesky)");
@@ -952,7 +1010,7 @@ static int32_t project_impl(bh_proj* P, const double* r, double* v_out, bool dev
     BH_TRY(stage_vec(P->rpad, r, P->n, dev));
     BH_TRY(launch_project(P, P->rpad, P->vtmp, nullptr));
     BH_TRY(fetch_vec(v_out, P->vtmp, P->n, dev));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 int32_t bh_project(bh_proj* P, const double* r, double* v_out) { return project_impl(P, r, v_out, false); }
@@ -967,7 +1025,7 @@ int32_t bh_left_mul(bh_proj* P, const double* x, double* out_mpp) {
     if (grid1 > 0) hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, P->rpad);
     BH_HIP(hipGetLastError());
     BH_TRY(fetch_vec(out_mpp, P->tw, P->mA + P->nfix, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -981,7 +1039,7 @@ int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
                        (const double*)nullptr, P->vtmp);
     BH_HIP(hipGetLastError());
     BH_TRY(fetch_vec(out_n, P->vtmp, P->n, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -1120,7 +1178,7 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     BH_TRY(pcg_run(H, P, gp, wlp, wup, wp, !in_place, kappa2, atol_negcurv, atol_f2b, trace_cap, &fin));
     if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
     if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));      // drains the over-launched no-op kernels; orders w for any consumer
+    BH_TRY(sync_flush());      // drains the over-launched no-op kernels; orders w for any consumer
     BH_TRY(pcg_finish(H, fin));
     if (status) *status = fin.status;
     if (iters) *iters = fin.iter;
@@ -1173,7 +1231,7 @@ int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const doubl
     BH_TRY(stage_vec(c.wu, w_u, n, false));
     BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, false));
     BH_TRY(fetch_vec(alpha_out, c.scalars, 1, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -1207,7 +1265,7 @@ int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* 
         BH_TRY(fetch_vec(&alpha, c.scalars, 1, false));
     }
     BH_TRY(fetch_vec(w_out, c.w, n, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     BH_TRY(pcg_finish(H, fin));
     if (status) *status = fin.status;
     if (iters) *iters = fin.iter;
@@ -1224,7 +1282,7 @@ int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out) 
     BH_TRY(stage_vec(H->upad + H->d, ybar, H->q, false));
     BH_TRY(launch_jtv(H, H->upad, H->zpad, true));
     BH_TRY(fetch_vec(g_out, H->zpad, H->n, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     H->stats.n_jtv += 1;
     return BH_OK;
 }
@@ -1242,7 +1300,7 @@ int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* ou
     const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
     hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, (const double*)c.g, H->zpad, (int)n);
     BH_TRY(fetch_vec(out_n, H->zpad, n, false));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     H->stats.n_hmul += 1;
     return BH_OK;
 }
@@ -1252,7 +1310,7 @@ int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* ou
 static int32_t adopt_mask(bh_proj* P, const std::vector<int>& rank, const std::vector<int>& idx) {
     BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
     if (!idx.empty()) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -1332,7 +1390,7 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     BH_HIP(hipMemcpyAsync(mask.data(), P->fixrank, (size_t)P->ldA * sizeof(int), hipMemcpyDeviceToHost, s));
     int info_host = 0;
     if (mA > 0) BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, s));
-    BH_HIP(hipStreamSynchronize(s));
+    BH_TRY(sync_flush());
     H->stats.n_hmul += mw.n_hmul;
     if (!mw.done) return fail(BH_ERR_HIP, "internal: Cauchy loop did not terminate");
     // canonical bookkeeping for the final active set
@@ -1386,13 +1444,13 @@ int32_t bh_dev_free(void* p) { dev_free(p); return BH_OK; }
 int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
     BH_REQUIRE_INIT();
     BH_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, g_ctx.stream));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
     BH_REQUIRE_INIT();
     BH_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -1449,7 +1507,7 @@ int32_t bh_selftest(void) {
     BH_HIP(hipMemcpyAsync(g_ctx.scratch_dev, host_in, sizeof(host_in), hipMemcpyHostToDevice, g_ctx.stream));
     hipLaunchKernelGGL(selftest_wave_kernel, dim3(1), dim3(256), 0, g_ctx.stream, g_ctx.scratch_dev, g_ctx.scratch_dev + 256);
     BH_HIP(hipMemcpyAsync(host_out, g_ctx.scratch_dev + 256, sizeof(host_out), hipMemcpyDeviceToHost, g_ctx.stream));
-    BH_HIP(hipStreamSynchronize(g_ctx.stream));
+    BH_TRY(sync_flush());
     for (int w = 0; w < 4; ++w) {
         double mn = host_in[64 * w];
         long double s = 0;

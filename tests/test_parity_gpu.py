@@ -629,3 +629,21 @@ def test_wide_jacobian_column_panels(bh, d, n, q):
     w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
     assert int(status) == int(s_ref) and info["iters"] == it_ref
     assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+
+
+def test_config4_sized_shard_on_one_gpu(bh):
+    """A 16 GiB image (d = 524288, n = 4096: all of BASELINE config 4 on one GPU) — 64-bit indexing, size-independent
+    properties and rows checked against the host generator."""
+    d, n = 524288, 4096
+    H = bh.AlHessian.synthetic(d, n, seed=3, mu=10.0)
+    rng = np.random.default_rng(1)
+    v, w = rng.standard_normal(n), rng.standard_normal(n)
+    Jv = H.jv(v)
+    for i in (0, 65535, 65536, 300000, d - 1):
+        Ji = R.synthetic_J(1, n, seed=3, row0=int(i), d_total=d)
+        assert abs(Jv[i] - float(Ji[0] @ v)) <= 1e-12 * float(np.abs(Ji[0]) @ np.abs(v))
+    Hv = H * v
+    assert relnorm(H.jtv(Jv), Hv) <= 1e-12
+    assert abs(v @ Hv - Jv @ Jv) <= 1e-12 * (Jv @ Jv)
+    assert relnorm(H * (v + 2 * w), Hv + 2 * (H * w)) <= 1e-12
+    H.close()
