@@ -48,6 +48,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
     int64_t opt_pingpong = 0;        // alternate the sweep direction of J between consecutive H*p products (A/B: +1 % without nt loads, -0.2 % with)
     // RCCL
@@ -337,7 +338,8 @@ int32_t launch_jtv_panels(bh_hess* H, const double* u, double* z_out, int64_t nr
 }
 
 // z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
-int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0) {
+int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0,
+                    bool negate = false, const int* negmask = nullptr) {
     const int64_t nrows = H->d + H->q_eff;
     if (multi_panel(H)) {
         BH_TRY(launch_jv_panels(H, v_pad, H->tbuf, nrows, state));
@@ -349,6 +351,7 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
     const int grid = grid_for(cfg, nrows);
     RowStreamArgs a = rs_args(H, nrows, state);
     a.v = v_pad; a.partials = H->partials; a.reverse = reverse;
+    a.negate = negate ? 1 : 0; a.negmask = negmask;
     // BH_FLAG_PROFILE: hipEvents around every kEvStride-th H*p launch of this handle, counted ACROSS calls (an event pair
     // costs ~10 us of stream time; timing every launch would slow the loop it measures by 3 %).
     bool timed = false;
@@ -570,6 +573,14 @@ void launch_cg_step(const CgArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((cg_step_kernel<PHASE>), dim3(1), dim3(CG_T), 0, s, a);
 }
 
+// First pass of a box-constrained CG with the initialisation folded in (n <= 8192).
+void launch_cg_first_step(const CgArgs& a, hipStream_t s) {
+    const int nch = (a.n + 1) / 2;
+    if (nch <= CG_T) hipLaunchKernelGGL((cg_step_reg_kernel<1, 0, true>), dim3(1), dim3(CG_T), 0, s, a);
+    else if (nch <= 2 * CG_T) hipLaunchKernelGGL((cg_step_reg_kernel<2, 0, true>), dim3(1), dim3(CG_T), 0, s, a);
+    else hipLaunchKernelGGL((cg_step_reg_kernel<4, 0, true>), dim3(1), dim3(CG_T), 0, s, a);
+}
+
 size_t trsv_lds_bytes(int m) { return ((size_t)((m + 1) & ~1) + 64 * 65) * sizeof(double); }
 
 // v_out = P(r_pad): r_pad is a zero-padded ldA-length device vector, v_out has >= n entries.
@@ -696,6 +707,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(1, value); return BH_OK; }
     if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }
@@ -1069,7 +1081,15 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     a.mirror = c.d_mirror; a.tag = c.tag;
 
     const bool box = (P->mA == 0);
-    if (box) {
+    // Box constraints with register-resident vectors: no init kernel — the first H*p forms p0 = -mask(g) on the fly and
+    // the first step kernel does the initialisation of :702-718 itself.
+    // (g doubles as the H*p input there, so it must be readable up to the padded length: workspace copy or n == ld.)
+    const bool fold_init = box && !multi_panel(H) && ((n + 1) / 2 <= 4 * CG_T) && max_iter >= 1 && g_ctx.opt_fold_init &&
+                           (gp == c.g || n == n_pad);
+    if (fold_init) {
+        if (gp == c.g && n < n_pad)   // stale padding of the staged g would be multiplied into the dot products
+            BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
+    } else if (box) {
         hipLaunchKernelGGL((cg_init_kernel<true>), dim3(1), dim3(CG_T), 0, s, a);
     } else {
         hipLaunchKernelGGL((cg_init_kernel<false>), dim3(1), dim3(CG_T), 0, s, a);
@@ -1079,6 +1099,12 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     BH_HIP(hipGetLastError());
 
     auto launch_iteration = [&](int index) -> int32_t {
+        if (fold_init && index == 0) {
+            // the state still holds the previous call's `done`: this launch is never a no-op, so it is not gated
+            BH_TRY(launch_hmul(H, gp, c.Hp, nullptr, index, 0, true, a.fixrank));                 // :722 with p = -P(g)
+            launch_cg_first_step(a, s);
+            return BH_OK;
+        }
         BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, index, g_ctx.opt_pingpong ? (index & 1) : 0));   // :722
         if (box) {
             launch_cg_step<0>(a, s);

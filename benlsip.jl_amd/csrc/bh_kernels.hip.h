@@ -127,6 +127,8 @@ struct RowStreamArgs {
     int reverse;            // sweep the row groups last-to-first (ping-pong order keeps the tail of J in the Infinity Cache)
     int accumulate;         // JV: t_out += (column panels of a wide J are swept one launch each)
     int weighted_u;         // JTV: coefficient u[row] * (row < d_rows ? 1 : mu)  (second pass of the two-pass H*p)
+    int negate;             // JV/FUSED: use -mask(v) instead of v (first CG iteration: p0 = -P(g) for box constraints, :706-708)
+    const int* negmask;     // fixrank (>= 0: fixed -> 0) or NULL, with negate
 };
 
 // NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
@@ -148,7 +150,15 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
         act[k] = c < a.nchunks;
         vv[k] = make_double2(0.0, 0.0);
         zz[k] = make_double2(0.0, 0.0);
-        if (MODE != MODE_JTV && act[k]) vv[k] = reinterpret_cast<const double2*>(a.v)[c];
+        if (MODE != MODE_JTV && act[k]) {
+            vv[k] = reinterpret_cast<const double2*>(a.v)[c];
+            if (a.negate) {
+                int2 f = make_int2(-1, -1);
+                if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
+                vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
+                vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
+            }
+        }
     }
 
     const int64_t ngroups = (a.nrows + R - 1) / R;
@@ -606,23 +616,31 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
 //   PHASE 0: box constraints, everything fused (projection = mask).
 //   PHASE 1: general constraints, step_a (pHp, gamma, branch, w and r updates; sets need_proj).
 //   PHASE 2: general constraints, step_b after v = P(r) (rtv_next, beta, p, exit test).
-template <int CH, int PHASE>
+//   FIRST (PHASE 0 only): the first pass also does the initialisation of projected_cg (:702-718: w = 0, r = g,
+//   v = P(r), rtv, p = -v, tol_cg) — no separate init kernel; the preceding H*p launch forms p0 = -mask(g) on the fly.
+template <int CH, int PHASE, bool FIRST = false>
 __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
     constexpr int NW = CG_T / 64;
-    __shared__ double scratch[2 * NW];
+    __shared__ double scratch[4 * NW];
     CgState* st = a.st;
-    if (st->done) return;
+    if (!FIRST && st->done) return;
     if (PHASE == 2 && !st->need_proj) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     const double QNAN = __longlong_as_double(0x7ff8000000000000ll);
     const int nch = (a.n + 1) >> 1;
-    const double rtv = st->rtv, tol_cg = st->tol_cg;
-    const int iter0 = st->iter, max_iter = st->max_iter, n_hmul0 = st->n_hmul;
+    double rtv = FIRST ? 0.0 : st->rtv, tol_cg = FIRST ? 0.0 : st->tol_cg;
+    const int iter0 = FIRST ? 1 : st->iter, max_iter = FIRST ? a.max_iter : st->max_iter, n_hmul0 = FIRST ? 0 : st->n_hmul;
 
     bool act[CH];
     double2 p[CH], hp[CH], w[CH], wl[CH], wu[CH], r[CH], v[CH];
     int2 fr[CH];
+    if (FIRST) {   // stale padding from an earlier, larger problem (the workspace is shared by all calls)
+        for (int i = a.n + tid; i < a.n_pad; i += CG_T) {
+            a.r[i] = 0.0; a.v[i] = 0.0; a.p[i] = 0.0;
+            if (a.w_in_ws) a.w[i] = 0.0;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         const int c = tid + k * CG_T;
@@ -630,11 +648,16 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         p[k] = hp[k] = w[k] = wl[k] = wu[k] = r[k] = v[k] = make_double2(0.0, 0.0);
         fr[k] = make_int2(-1, -1);
         if (act[k]) {
-            p[k] = reinterpret_cast<const double2*>(a.p)[c];
-            r[k] = reinterpret_cast<const double2*>(a.r)[c];
+            if (FIRST) {
+                r[k] = reinterpret_cast<const double2*>(a.g)[c];          // r = g_minor (:705)
+                if ((2 * c + 1) >= a.n) r[k].y = 0.0;                     // odd n: never trust the element past the end
+            } else {
+                p[k] = reinterpret_cast<const double2*>(a.p)[c];
+                r[k] = reinterpret_cast<const double2*>(a.r)[c];
+            }
             if (PHASE != 2) {
                 hp[k] = reinterpret_cast<const double2*>(a.Hp)[c];
-                w[k] = reinterpret_cast<const double2*>(a.w)[c];
+                if (!FIRST) w[k] = reinterpret_cast<const double2*>(a.w)[c];   // w = 0 (:702)
                 wl[k] = reinterpret_cast<const double2*>(a.wl)[c];
                 wu[k] = reinterpret_cast<const double2*>(a.wu)[c];
             } else {
@@ -650,7 +673,17 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
     if (PHASE != 2) {
         // pHp = dot(p,Hp) (:723); gamma = factor_to_boundary(p,w,w_l,w_u) (:728,:734).  Padding elements are zeros: no effect.
         OpMinNan opmin;
-        double sum = 0.0, gmin = INF;
+        double sum = 0.0, gmin = INF, rtv0 = 0.0, vv0 = 0.0;
+        if (FIRST) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if (a.fixrank != nullptr && act[k]) fr[k] = reinterpret_cast<const int2*>(a.fixrank)[tid + k * CG_T];
+                const double v0x = (fr[k].x >= 0) ? 0.0 : r[k].x, v0y = (fr[k].y >= 0) ? 0.0 : r[k].y;   // v = P(r) (:706)
+                rtv0 = fma(r[k].x, v0x, rtv0); rtv0 = fma(r[k].y, v0y, rtv0);                            // :707
+                vv0 = fma(v0x, v0x, vv0); vv0 = fma(v0y, v0y, vv0);                                      // :710
+                p[k].x = -v0x; p[k].y = -v0y;                                                            // :708
+            }
+        }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             sum = fma(p[k].x, hp[k].x, sum);
@@ -660,10 +693,21 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         }
         sum = wave_sum(sum);
         gmin = wave_min(gmin);
-        if (lane == 0) { scratch[wave] = sum; scratch[NW + wave] = gmin; }
+        if (FIRST) { rtv0 = wave_sum(rtv0); vv0 = wave_sum(vv0); }
+        if (lane == 0) {
+            scratch[wave] = sum; scratch[NW + wave] = gmin;
+            if (FIRST) { scratch[2 * NW + wave] = rtv0; scratch[3 * NW + wave] = vv0; }
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NW; ++i) { pHp += scratch[i]; gamma = opmin(gamma, scratch[NW + i]); }
+        if (FIRST) {
+            rtv = 0.0;
+            double vv = 0.0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { rtv += scratch[2 * NW + i]; vv += scratch[3 * NW + i]; }
+            tol_cg = a.kappa2 * sqrt(vv);               // :710
+        }
         __syncthreads();   // scratch is reused below
 
         if (pHp <= a.atol_neg) {                        // :725
@@ -727,14 +771,14 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         if (!act[k]) continue;
         const bool full = (2 * c + 1) < a.n;
         if (full) {
-            if (PHASE != 2 && add_w) reinterpret_cast<double2*>(a.w)[c] = w[k];
+            if (PHASE != 2 && (add_w || FIRST)) reinterpret_cast<double2*>(a.w)[c] = w[k];
             if (cont) {
                 if (PHASE != 2) reinterpret_cast<double2*>(a.r)[c] = r[k];
                 if (PHASE == 0) reinterpret_cast<double2*>(a.v)[c] = v[k];
                 if (PHASE != 1) reinterpret_cast<double2*>(a.p)[c] = p[k];
             }
         } else {
-            if (PHASE != 2 && add_w) a.w[2 * c] = w[k].x;
+            if (PHASE != 2 && (add_w || FIRST)) a.w[2 * c] = w[k].x;
             if (cont) {
                 if (PHASE != 2) a.r[2 * c] = r[k].x;
                 if (PHASE == 0) a.v[2 * c] = v[k].x;
@@ -745,6 +789,10 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
     if (tid == 0) {
         const int n_hmul = (PHASE == 2) ? n_hmul0 : n_hmul0 + 1;
         bool write_trace = false;
+        if (FIRST) {
+            st->rtv = rtv; st->tol_cg = tol_cg; st->beta = 0.0;
+            st->iter = 1; st->max_iter = max_iter; st->approx_solved = 0; st->done = 0; st->status = 4;
+        }
         if (PHASE != 2) {
             st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = n_hmul;
             st->neg_curvature = neg; st->outside_region = outside;
