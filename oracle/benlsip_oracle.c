@@ -27,7 +27,7 @@ int bo_num_threads(void) {
 
 /* t = J v  (dgemv 'N'), J d x n column-major.  Row blocks per thread, columns streamed with unit stride. */
 static void gemv_n(const double* J, long d, long n, long ld, const double* v, double* t) {
-#pragma omp parallel
+#pragma omp parallel if (d * n > 2000000L)   /* small products: a parallel region costs more than the product */
     {
         int nt = 1, id = 0;
 #ifdef _OPENMP
@@ -49,7 +49,7 @@ static void gemv_n(const double* J, long d, long n, long ld, const double* v, do
 
 /* z = J' t  (dgemv 'T'): one dot product per column. */
 static void gemv_t(const double* J, long d, long n, long ld, const double* t, double* z) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) if (d * n > 2000000L)
     for (long j = 0; j < n; ++j) {
         const double* col = J + j * ld;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
