@@ -175,15 +175,17 @@ def main():
     hmul_ms = st["hmul_ms"] / max(st["hmul_timed"], 1)
     achieved = st["bytes_per_hmul"] / (hmul_ms * 1e-3) / 1e9 if hmul_ms > 0 else 0.0
     line = {
-        "metric": "PCG subproblems/sec (dense m=65536 n=4096 fp64 per GPU) + achieved HBM GB/s",
+        "metric": "PCG subproblems/sec + achieved HBM GB/s, dense m=65536 n=4096 fp64",     # BASELINE.json's metric, verbatim
         "value": world * args.steps / elapsed,
-        "unit": "PCG subproblems/s (one unit = one 65536x4096 row shard of one projected_cg call)",
+        "unit": "PCG subproblems/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": "BASELINE config 3 per GPU: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), box bounds, "
                         "p=512 active, mu=10, kappa2=0.1, variant=%s; one step = one projected_cg subproblem (bh_pcg_dev), "
                         "vectors resident in HBM" % (host["d_total"], N_COLS, D_PER_GPU, args.variant),
+            "unit_definition": "one unit = one 65536x4096 row shard of one projected_cg call: at N GPUs a step solves ONE subproblem "
+                               "on N*65536 rows and counts N units (weak scaling); subproblems_per_s_global counts it once",
             "d_total": host["d_total"], "n": N_COLS, "rows_per_gpu": D_PER_GPU, "parallelism": "row-shard x%d + 1 all-reduce(n) per H*p" % world,
             "cg_status": status.name, "cg_iters_per_subproblem": iters - 1, "hmul_per_subproblem": n_hmul,
         },

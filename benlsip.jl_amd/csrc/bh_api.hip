@@ -1189,9 +1189,10 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     const int64_t n = H->n;
     BH_TRY(ensure_cg_workspace(H->ld, trace_cap));
     CgWorkspace& c = g_ctx.cg;
-    // Device callers with even n hand over buffers the kernels can use in place (16-byte chunk loads stay in bounds);
-    // host callers and odd n go through the zero-padded workspace.
-    const bool in_place = dev && (n % 2 == 0);
+    // Device callers with even n and 16-byte aligned buffers hand over memory the kernels can use in place (16-byte chunk
+    // loads stay in bounds); host callers, odd n and unaligned pointers go through the zero-padded workspace.
+    auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool in_place = dev && (n % 2 == 0) && aligned16(g_minor) && aligned16(w_l) && aligned16(w_u) && aligned16(w_out);
     const double *gp = g_minor, *wlp = w_l, *wup = w_u;
     double* wp = w_out;
     if (!in_place) {

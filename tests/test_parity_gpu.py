@@ -25,7 +25,7 @@ def _flt(xs):
 
 
 # ----------------------------------------------------------------------------- operators
-@pytest.mark.parametrize("d,n,q", [(4, 3, 1), (1, 1, 0), (5, 5, 5), (37, 5, 2), (64, 128, 0), (300, 130, 0), (257, 129, 1),
+@pytest.mark.parametrize("d,n,q", [(4, 3, 1), (1, 1, 0), (0, 5, 2), (5, 5, 5), (37, 5, 2), (64, 128, 0), (300, 130, 0), (257, 129, 1),
                                    (1000, 1024, 3), (513, 2049, 0), (256, 4096, 2), (100, 4095, 0), (130, 8000, 1),
                                    (8192, 1024, 0), (3, 600, 0)])
 def test_matvec_parity(bh, d, n, q):
