@@ -395,6 +395,8 @@ struct CgArgs {
     int max_iter;
     double kappa2, atol_neg, atol_f2b;
     double* trace; int trace_cap;
+    double* hw;                   // NULL, or H*w accumulated alongside w (hw += step*Hp): lets minor_iterate's linesearch form
+                                  // w'Hw = w.hw without another sweep over J (src/basic_tralcnlss.jl:775 calls vthv(H,w))
     unsigned long long* mirror;   // host-mapped word the host polls instead of copying CgState back (NULL: none)
     unsigned tag;                 // per-call tag stored in the mirror's top 16 bits
 };
@@ -434,11 +436,13 @@ __global__ __launch_bounds__(CG_T) void cg_init_kernel(CgArgs a) {
     for (int i = a.n + threadIdx.x; i < a.n_pad; i += CG_T) {     // stale padding from an earlier, larger problem
         a.r[i] = 0.0; a.v[i] = 0.0; a.p[i] = 0.0;
         if (a.w_in_ws) a.w[i] = 0.0;
+        if (a.hw != nullptr) a.hw[i] = 0.0;
     }
     for (int i = threadIdx.x; i < a.n; i += CG_T) {
         const double ri = a.g[i];
         a.r[i] = ri;
         a.w[i] = 0.0;
+        if (a.hw != nullptr) a.hw[i] = 0.0;
         if (BOX) {
             const double vi = (a.fixrank != nullptr && a.fixrank[i] >= 0) ? 0.0 : ri;
             a.v[i] = vi;
@@ -536,6 +540,8 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
         const bool add_w = !(neg && !(fabs(pHp) > a.atol_neg));
         if (add_w) {
             for (int i = tid; i < a.n; i += CG_T) a.w[i] = __dadd_rn(a.w[i], __dmul_rn(step, a.p[i]));
+            if (a.hw != nullptr)
+                for (int i = tid; i < a.n; i += CG_T) a.hw[i] = __dadd_rn(a.hw[i], __dmul_rn(step, a.Hp[i]));
         }
         if (tid == 0) {
             st->pHp = pHp; st->gamma = gamma; st->alpha = (pHp <= a.atol_neg) ? __longlong_as_double(0x7ff8000000000000ll) : alpha;
@@ -639,12 +645,16 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         for (int i = a.n + tid; i < a.n_pad; i += CG_T) {
             a.r[i] = 0.0; a.v[i] = 0.0; a.p[i] = 0.0;
             if (a.w_in_ws) a.w[i] = 0.0;
+            if (a.hw != nullptr) a.hw[i] = 0.0;
         }
     }
+    double2 hw[CH];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
         const int c = tid + k * CG_T;
         act[k] = c < nch;
+        hw[k] = make_double2(0.0, 0.0);
+        if (PHASE != 2 && !FIRST && a.hw != nullptr && act[k]) hw[k] = reinterpret_cast<const double2*>(a.hw)[c];
         p[k] = hp[k] = w[k] = wl[k] = wu[k] = r[k] = v[k] = make_double2(0.0, 0.0);
         fr[k] = make_int2(-1, -1);
         if (act[k]) {
@@ -725,6 +735,8 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
             for (int k = 0; k < CH; ++k) {
                 w[k].x = __dadd_rn(w[k].x, __dmul_rn(step, p[k].x));
                 w[k].y = __dadd_rn(w[k].y, __dmul_rn(step, p[k].y));
+                hw[k].x = __dadd_rn(hw[k].x, __dmul_rn(step, hp[k].x));    // H*w rides along (a.hw)
+                hw[k].y = __dadd_rn(hw[k].y, __dmul_rn(step, hp[k].y));
             }
         }
         if (cont) {
@@ -772,6 +784,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         const bool full = (2 * c + 1) < a.n;
         if (full) {
             if (PHASE != 2 && (add_w || FIRST)) reinterpret_cast<double2*>(a.w)[c] = w[k];
+            if (PHASE != 2 && (add_w || FIRST) && a.hw != nullptr) reinterpret_cast<double2*>(a.hw)[c] = hw[k];
             if (cont) {
                 if (PHASE != 2) reinterpret_cast<double2*>(a.r)[c] = r[k];
                 if (PHASE == 0) reinterpret_cast<double2*>(a.v)[c] = v[k];
@@ -779,6 +792,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
             }
         } else {
             if (PHASE != 2 && (add_w || FIRST)) a.w[2 * c] = w[k].x;
+            if (PHASE != 2 && (add_w || FIRST) && a.hw != nullptr) a.hw[2 * c] = hw[k].x;
             if (cont) {
                 if (PHASE != 2) a.r[2 * c] = r[k].x;
                 if (PHASE == 0) a.v[2 * c] = v[k].x;
@@ -846,14 +860,15 @@ __global__ __launch_bounds__(256) void step_bounds_kernel(const double* __restri
 __global__ __launch_bounds__(CG_T) void linesearch_kernel(const double* __restrict__ g, double* __restrict__ w,
                                                           const double* __restrict__ wl, const double* __restrict__ wu,
                                                           const int* __restrict__ fixrank, const double* __restrict__ wHw_p,
-                                                          int n, int scale_w, double* __restrict__ out) {
+                                                          const double* __restrict__ hw, int n, int scale_w, double* __restrict__ out) {
     __shared__ double scratch[2 * (CG_T / 64)];
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     OpMinNan opmin;
-    double gw[1] = {0.0}, amin[1] = {INF};
+    double gw[1] = {0.0}, amin[1] = {INF}, whw[1] = {0.0};
     for (int i = threadIdx.x; i < n; i += CG_T) {
         const double wi = w[i];
         gw[0] = fma(g[i], wi, gw[0]);
+        if (hw != nullptr) whw[0] = fma(wi, hw[i], whw[0]);      // w'Hw from the H*w the CG loop accumulated
         if (fixrank == nullptr || fixrank[i] < 0) {              // :781
             if (wi < 0.0) amin[0] = opmin(amin[0], __ddiv_rn(wl[i], wi));      // :783
             else if (wi > 0.0) amin[0] = opmin(amin[0], __ddiv_rn(wu[i], wi)); // :785
@@ -861,7 +876,8 @@ __global__ __launch_bounds__(CG_T) void linesearch_kernel(const double* __restri
     }
     block_reduce<CG_T, 1>(gw, scratch, OpSum(), 0.0);
     block_reduce<CG_T, 1>(amin, scratch, opmin, INF);
-    const double wHw = wHw_p[0];
+    if (hw != nullptr) block_reduce<CG_T, 1>(whw, scratch, OpSum(), 0.0);
+    const double wHw = (hw != nullptr) ? whw[0] : wHw_p[0];
     const double alpha_opt = (wHw > 0.0) ? __ddiv_rn(-gw[0], wHw) : INF;      // :776
     const double alpha = opmin(alpha_opt, amin[0]);                            // :790
     if (scale_w)

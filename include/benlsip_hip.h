@@ -25,6 +25,7 @@
  *   - multi-GPU: rows of J are sharded over ranks (one process per GPU); each
  *     rank passes its own row block to bh_hess_create*.  After bh_comm_init every
  *     J'·(…) product ends in ONE RCCL all-reduce of n doubles.
+ *     Call bh_comm_init BEFORE creating handles (rank 0 alone applies the replicated C rows).
  */
 #ifndef BENLSIP_HIP_H
 #define BENLSIP_HIP_H
@@ -165,7 +166,9 @@ int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const doub
 /* minor_iterate(x, s, g_model, H, lincons, delta, kappa2) — src/basic_tralcnlss.jl:649-675: builds w_l/w_u exactly as :660-665
  * (only the FIXED variables get finite bounds), runs projected_cg (:667) and, unless the status is
  * negative_curvature, linesearch and w .= alpha*w (:669-672) — one call, no intermediate PCIe round trips.
- * xlow/xupp = lincons.xlow/xupp.  alpha_out (optional) receives the line-search factor (NaN when it was skipped). */
+ * xlow/xupp = lincons.xlow/xupp.  alpha_out (optional) receives the line-search factor (NaN when it was skipped).
+ * The line search's w'Hw is taken from H*w accumulated inside the CG loop (option "ls_from_cg", default 1) instead of a
+ * separate vthv(H,w) sweep; same value up to rounding. */
 int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* s, const double* g_model,
                          const double* xlow, const double* xupp, double delta, double kappa2,
                          double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters,

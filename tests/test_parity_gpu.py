@@ -560,6 +560,16 @@ def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
     assert relnorm(w, w_ref) <= 10 * tol, (relnorm(w, w_ref), tol)
     if int(st_ref) != int(R.CGStatus.negative_curvature):
         assert info["alpha"] == pytest.approx(R.linesearch(gm_ref, Ho, w_cg, wl2, wu2, cons_o.fixvars), rel=1e-6)
+    # default: w'Hw from the H*w the CG loop accumulated; option 0: the reference's explicit vthv(H, w) (:775).  Same value.
+    bh._lib.lib().bh_set_option(b"ls_from_cg", 0)
+    try:
+        w2, st2, info2 = bh.minor_iterate(x, s, gm_ref, H, cons, delta, 0.1, full_output=True)
+    finally:
+        bh._lib.lib().bh_set_option(b"ls_from_cg", 1)
+    assert int(st2) == int(st) and info2["iters"] == info["iters"]
+    if int(st_ref) != int(R.CGStatus.negative_curvature):
+        assert info2["alpha"] == pytest.approx(info["alpha"], rel=1e-10)
+        assert relnorm(w2, w) <= 1e-10
 
 
 # ----------------------------------------------------------------------------- Cauchy step on the device (f-3)
