@@ -13,4 +13,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 grep '^{' $OUT/trace.log > $OUT/bench_line_under_trace.json || true
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $OUT/write.log 2>&1
+# clock / stall picture of the same run (SQ and GRBM slots are independent of TCC)
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $OUT/sq -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $OUT/sq.log 2>&1 || true
 find $OUT -name "*.csv" | head -20

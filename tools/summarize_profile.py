@@ -43,6 +43,22 @@ def main(tag):
         if f is not None and w is not None:
             entry["hbm_bytes_per_launch"] = 2.0 * f * 1024.0 + w * 1024.0
         out["kernels"][name] = entry
+    sq_files = sorted(glob.glob(os.path.join(src, "sq", "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
+    if sq_files:
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(sq_files[0])):
+            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        sq = {}
+        for name, cs in acc.items():
+            e = {k + "_avg": sum(v) / len(v) for k, v in cs.items()}
+            e["avg_duration_ns_under_pmc"] = sum(dur[name]) / len(dur[name])
+            if "GRBM_GUI_ACTIVE_avg" in e and e["avg_duration_ns_under_pmc"] > 0:
+                # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+                e["effective_clock_GHz"] = e["GRBM_GUI_ACTIVE_avg"] / 8.0 / e["avg_duration_ns_under_pmc"]
+            sq[name] = e
+        out["sq_counters"] = sq
     json.dump(out, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
     for name, e in out["kernels"].items():
         if "hbm_bytes_per_launch" in e:
