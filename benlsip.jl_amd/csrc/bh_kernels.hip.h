@@ -1180,6 +1180,59 @@ __global__ __launch_bounds__(256) void gram_free_kernel(const double* __restrict
     if (lane == 0) M[i + (int64_t)k * mA] = acc;
 }
 
+// M = A_free A_free' on the matrix cores: the one genuinely GEMM-shaped product around the hot path (mA x n x mA, fp64).
+// One workgroup (4 waves) per 16 x 16 lower tile; v_mfma_f64_16x16x4_f64 with A_op[i][k] = Af[16 ti + i][c + k],
+// B_op[k][j] = Af[16 tk + j][c + k]  (lane l holds i or j = l & 15 and k = l >> 4; C/D: col = l & 15, row = (l >> 4) + 4 reg).
+// The k index is permuted so that lane group l >> 4 owns 4 CONSECUTIVE columns per 16-column super-step (one 32-byte load
+// per lane and operand, 128 contiguous bytes per matrix row); the 4 waves split the super-steps and are combined through
+// LDS in fixed order (bit-reproducible).  Fixed variables are masked out of the A operand (A_free = A with those columns 0).
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gram_free_mfma_kernel(const double* __restrict__ A, int64_t ldA, int mA,
+                                                             const int* __restrict__ fixrank, double* __restrict__ M) {
+    __shared__ double red[4][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // packed lower-triangular tile index -> (ti, tk), ti >= tk
+    const int e = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+    while (ti * (ti + 1) / 2 > e) --ti;
+    const int tk = e - ti * (ti + 1) / 2;
+    const int ri = 16 * ti + (lane & 15), rk = 16 * tk + (lane & 15), kq = lane >> 4;
+    const bool vi = ri < mA, vk = rk < mA;
+    const double* pa = A + (int64_t)(vi ? ri : 0) * ldA + 4 * kq;
+    const double* pb = A + (int64_t)(vk ? rk : 0) * ldA + 4 * kq;
+    const int nsuper = (int)(ldA >> 4);          // 16 columns per super-step (ldA is a multiple of 16)
+    dvec4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (int sidx = wave; sidx < nsuper; sidx += 4) {
+        const int64_t c = (int64_t)sidx * 16;
+        double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
+        if (vi) { a01 = *reinterpret_cast<const double2*>(pa + c); a23 = *reinterpret_cast<const double2*>(pa + c + 2); }
+        if (vk) { b01 = *reinterpret_cast<const double2*>(pb + c); b23 = *reinterpret_cast<const double2*>(pb + c + 2); }
+        if (fixrank != nullptr) {
+            const int4 f = *reinterpret_cast<const int4*>(fixrank + c + 4 * kq);
+            if (f.x >= 0) a01.x = 0.0;
+            if (f.y >= 0) a01.y = 0.0;
+            if (f.z >= 0) a23.x = 0.0;
+            if (f.w >= 0) a23.y = 0.0;
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double t = (red[0][lane][r] + red[1][lane][r]) + (red[2][lane][r] + red[3][lane][r]);
+        const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tk + (lane & 15);
+        if (row < mA && col <= row) M[row + (int64_t)col * mA] = t;
+    }
+}
+
 // In-place lower Cholesky of the mA x mA matrix M (column-major, lower triangle), single workgroup, right-looking.
 // info[0] = 0 on success, else 1 + index of the first non-positive pivot (the reference's PosDefException).
 __global__ __launch_bounds__(CG_T) void chol_lower_kernel(const double* __restrict__ Msrc, double* __restrict__ M, int m, int* info,

@@ -559,7 +559,9 @@ def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
     tol = w_tolerance(gm_ref, Ho, wl2, wu2, cons_o, 0.1, w_cg)
     assert relnorm(w, w_ref) <= 10 * tol, (relnorm(w, w_ref), tol)
     if int(st_ref) != int(R.CGStatus.negative_curvature):
-        assert info["alpha"] == pytest.approx(R.linesearch(gm_ref, Ho, w_cg, wl2, wu2, cons_o.fixvars), rel=1e-6)
+        a_cg = R.linesearch(gm_ref, Ho, w_cg, wl2, wu2, cons_o.fixvars)
+        # alpha = -g.w / w'Hw inherits the rounding sensitivity of w (tol, measured on the oracle itself)
+        assert info["alpha"] == pytest.approx(a_cg, rel=max(1e-6, 1e3 * tol)), (info["alpha"], a_cg, tol, relnorm(w, w_ref))
     # default: w'Hw from the H*w the CG loop accumulated; option 0: the reference's explicit vthv(H, w) (:775).  Same value.
     bh._lib.lib().bh_set_option(b"ls_from_cg", 0)
     try:
@@ -657,3 +659,28 @@ def test_config4_sized_shard_on_one_gpu(bh):
     assert abs(v @ Hv - Jv @ Jv) <= 1e-12 * (Jv @ Jv)
     assert relnorm(H * (v + 2 * w), Hv + 2 * (H * w)) <= 1e-12
     H.close()
+
+
+@pytest.mark.parametrize("mA,n,nfix", [(1, 40, 3), (5, 33, 0), (16, 100, 20), (17, 257, 60), (64, 1000, 300), (100, 700, 150)])
+def test_gram_on_matrix_cores_matches_valu_path(bh, mA, n, nfix):
+    """A_free A_free' via v_mfma_f64_16x16x4_f64 (default) against the one-wave-per-entry VALU kernel and the oracle:
+    the projections built from both factors agree with the reference projector."""
+    rng = np.random.default_rng(mA * 1000 + n)
+    A = rng.standard_normal((mA, n))
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, nfix, replace=False)] = True
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix if nfix else None)
+    r = rng.standard_normal(n)
+    v_ref = R.projection(cons_o, r)
+    lib = bh._lib.lib()
+    out = {}
+    for flag in (1, 0):
+        lib.bh_set_option(b"gram_mfma", flag)
+        cons = bh.MixedConstraints(A, None, fix)
+        out[flag] = bh.projection(cons, r)
+    lib.bh_set_option(b"gram_mfma", 1)
+    B = np.vstack([A, np.eye(n)[fix]])
+    tol = max(1e-11, 200 * np.finfo(float).eps * np.linalg.cond(B @ B.T))
+    assert np.linalg.norm(out[1] - v_ref) <= tol * np.linalg.norm(r)
+    assert np.linalg.norm(out[0] - v_ref) <= tol * np.linalg.norm(r)
+    assert np.linalg.norm(out[1] - out[0]) <= tol * np.linalg.norm(r)
