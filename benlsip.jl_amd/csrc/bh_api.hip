@@ -49,7 +49,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
-    int64_t opt_gram_mfma = 1;       // A_free A_free' on the matrix cores (0: one wave per entry, VALU)
+    int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
@@ -546,9 +546,11 @@ int32_t ensure_reduced_buffers(bh_proj* P) {
 // M = A_free A_free' from the device-side mask, then Lr = chol(M).  `gate`: skip when gate->done (in-loop use).
 int32_t launch_reduced_factor(bh_proj* P, bool use_mask, const CgState* gate) {
     const int mA = (int)P->mA;
-    if (g_ctx.opt_gram_mfma) {
+    // Measured (n = 4096): VALU kernel 12 us at mA = 64, 107 us at mA = 256; MFMA kernel ~33 us flat up to mA ~ 350 (one
+    // workgroup per tile leaves most CUs idle for few tiles) -> matrix cores from mA > 96; opt_gram_mfma = 2 forces them.
+    if ((g_ctx.opt_gram_mfma == 1 && mA > 96) || g_ctx.opt_gram_mfma == 2) {
         const int nt = (mA + 15) / 16;            // 16 x 16 lower tiles on the matrix cores (v_mfma_f64_16x16x4_f64)
-        hipLaunchKernelGGL(gram_free_mfma_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
+        hipLaunchKernelGGL(gram_free_mfma_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(GRAM_T), 0, g_ctx.stream, P->Ad, P->ldA, mA,
                            use_mask ? P->fixrank : (const int*)nullptr, P->M);
     } else {
         const int64_t pairs = (int64_t)mA * (mA + 1) / 2;
@@ -718,7 +720,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
-    if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }

@@ -1181,15 +1181,17 @@ __global__ __launch_bounds__(256) void gram_free_kernel(const double* __restrict
 }
 
 // M = A_free A_free' on the matrix cores: the one genuinely GEMM-shaped product around the hot path (mA x n x mA, fp64).
-// One workgroup (4 waves) per 16 x 16 lower tile; v_mfma_f64_16x16x4_f64 with A_op[i][k] = Af[16 ti + i][c + k],
+// One workgroup (16 waves) per 16 x 16 lower tile; v_mfma_f64_16x16x4_f64 with A_op[i][k] = Af[16 ti + i][c + k],
 // B_op[k][j] = Af[16 tk + j][c + k]  (lane l holds i or j = l & 15 and k = l >> 4; C/D: col = l & 15, row = (l >> 4) + 4 reg).
 // The k index is permuted so that lane group l >> 4 owns 4 CONSECUTIVE columns per 16-column super-step (one 32-byte load
-// per lane and operand, 128 contiguous bytes per matrix row); the 4 waves split the super-steps and are combined through
+// per lane and operand, 128 contiguous bytes per matrix row); the 16 waves split the super-steps and are combined through
 // LDS in fixed order (bit-reproducible).  Fixed variables are masked out of the A operand (A_free = A with those columns 0).
 typedef double dvec4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void gram_free_mfma_kernel(const double* __restrict__ A, int64_t ldA, int mA,
-                                                             const int* __restrict__ fixrank, double* __restrict__ M) {
-    __shared__ double red[4][64][4];
+constexpr int GRAM_T = 1024;     // 16 waves split the k range of one tile (a tile has only mA-independent work: n/16 super-steps)
+__global__ __launch_bounds__(GRAM_T) void gram_free_mfma_kernel(const double* __restrict__ A, int64_t ldA, int mA,
+                                                                const int* __restrict__ fixrank, double* __restrict__ M) {
+    constexpr int NW = GRAM_T / 64;
+    __shared__ double red[NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // packed lower-triangular tile index -> (ti, tk), ti >= tk
     const int e = blockIdx.x;
@@ -1202,9 +1204,9 @@ __global__ __launch_bounds__(256) void gram_free_mfma_kernel(const double* __res
     const double* pa = A + (int64_t)(vi ? ri : 0) * ldA + 4 * kq;
     const double* pb = A + (int64_t)(vk ? rk : 0) * ldA + 4 * kq;
     const int nsuper = (int)(ldA >> 4);          // 16 columns per super-step (ldA is a multiple of 16)
-    dvec4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-    for (int sidx = wave; sidx < nsuper; sidx += 4) {
+    dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two independent accumulation chains
+#pragma unroll 4
+    for (int sidx = wave; sidx < nsuper; sidx += NW) {
         const int64_t c = (int64_t)sidx * 16;
         double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
         if (vi) { a01 = *reinterpret_cast<const double2*>(pa + c); a23 = *reinterpret_cast<const double2*>(pa + c + 2); }
@@ -1216,18 +1218,20 @@ __global__ __launch_bounds__(256) void gram_free_mfma_kernel(const double* __res
             if (f.z >= 0) a23.x = 0.0;
             if (f.w >= 0) a23.y = 0.0;
         }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc1, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc0[r] + acc1[r];
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const double t = (red[0][lane][r] + red[1][lane][r]) + (red[2][lane][r] + red[3][lane][r]);
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][lane][r];
         const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tk + (lane & 15);
         if (row < mA && col <= row) M[row + (int64_t)col * mA] = t;
     }

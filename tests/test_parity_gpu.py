@@ -674,10 +674,10 @@ def test_gram_on_matrix_cores_matches_valu_path(bh, mA, n, nfix):
     v_ref = R.projection(cons_o, r)
     lib = bh._lib.lib()
     out = {}
-    for flag in (1, 0):
+    for flag in (2, 0):          # 2 = matrix cores for every mA, 0 = VALU kernel (default 1 switches at mA > 96)
         lib.bh_set_option(b"gram_mfma", flag)
         cons = bh.MixedConstraints(A, None, fix)
-        out[flag] = bh.projection(cons, r)
+        out[1 if flag else 0] = bh.projection(cons, r)
     lib.bh_set_option(b"gram_mfma", 1)
     B = np.vstack([A, np.eye(n)[fix]])
     tol = max(1e-11, 200 * np.finfo(float).eps * np.linalg.cond(B @ B.T))
