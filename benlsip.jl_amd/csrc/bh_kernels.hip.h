@@ -1257,13 +1257,20 @@ __global__ __launch_bounds__(CG_T) void chol_lower_kernel(const double* __restri
         const double piv = s_piv;
         for (int i = j + tid; i < m; i += CG_T) M[i + (int64_t)j * m] = (i == j) ? piv : M[i + (int64_t)j * m] / piv;
         __syncthreads();
-        // trailing update of the lower triangle: M[i][k] -= L[i][j]*L[k][j], j < k <= i
+        // trailing update of the lower triangle: M[i][k] -= L[i][j]*L[k][j], j < k <= i.  32 x 32 thread tiles over the
+        // lower triangle (tx along i: coalesced in the column-major matrix; no integer division per element).
         const int rem = m - j - 1;
-        for (int64_t e = tid; e < (int64_t)rem * rem; e += CG_T) {
-            const int kk = (int)(e / rem), ii = (int)(e - (int64_t)kk * rem);
-            if (ii >= kk) {
-                const int i = j + 1 + ii, k = j + 1 + kk;
-                M[i + (int64_t)k * m] = fma(-M[i + (int64_t)j * m], M[k + (int64_t)j * m], M[i + (int64_t)k * m]);
+        const int tx = tid & 31, ty = tid >> 5;
+        const double* colj = M + (int64_t)j * m + (j + 1);
+        for (int kb = 0; kb < rem; kb += 32) {
+            const int kk = kb + ty;
+            const double lkj = (kk < rem) ? colj[kk] : 0.0;
+            for (int ib = kb; ib < rem; ib += 32) {
+                const int ii = ib + tx;
+                if (ii < rem && kk < rem && ii >= kk) {
+                    double* e = M + (int64_t)(j + 1 + kk) * m + (j + 1 + ii);
+                    *e = fma(-colj[ii], lkj, *e);
+                }
             }
         }
         __syncthreads();
