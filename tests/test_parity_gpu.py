@@ -684,3 +684,32 @@ def test_gram_on_matrix_cores_matches_valu_path(bh, mA, n, nfix):
     assert np.linalg.norm(out[1] - v_ref) <= tol * np.linalg.norm(r)
     assert np.linalg.norm(out[0] - v_ref) <= tol * np.linalg.norm(r)
     assert np.linalg.norm(out[1] - out[0]) <= tol * np.linalg.norm(r)
+
+
+def test_pcg_config3_full_size_against_oracle(bh):
+    """BASELINE config 3 itself (d = 65536, n = 4096, box, p = 512; the bench.py workload): the device-generated J against the
+    host generator (full 2 GiB image through J v and J' u) and projected_cg against the oracle at full size."""
+    d, n = 65536, 4096
+    J = np.empty((d, n), order="F")
+    for r0 in range(0, d, 8192):                      # host generator in row slabs (bounds the temporaries)
+        J[r0:r0 + 8192] = R.synthetic_J(8192, n, seed=1, row0=r0, d_total=d)
+    inst = R.synthetic_box_vectors(d, n, fix_every=8)
+    H = bh.AlHessian.synthetic(d, n, seed=1, mu=10.0)
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal(n)
+    assert np.linalg.norm(H.jv(v) - J @ v) <= TOL1 * matvec_scale(J, v)
+    g = J.T @ inst.r0
+    assert np.linalg.norm(H.jtv(inst.r0) - g) <= TOL1 * matvec_scale(J.T, inst.r0)
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    Ho = R.AlHessian(J, np.zeros((0, n)), 10.0)
+    w_l, w_u = R.build_step_bounds(inst.x, cons_o, R.initial_tr(g))
+    cons = bh.MixedConstraints(A, None, inst.fixvars, l=inst.x_l, u=inst.x_u)
+    for kappa2 in (0.1, 1e-3):
+        tr = R.CGTrace()
+        w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, kappa2, trace=tr)
+        w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, kappa2, trace_cap=64, full_output=True)
+        assert int(status) == int(s_ref) and info["iters"] == it_ref and info["n_hmul"] == tr.n_hmul
+        assert relnorm(w, w_ref) <= 1e-9, relnorm(w, w_ref)
+        np.testing.assert_allclose(info["trace"], np.array(tr.rows), rtol=1e-9)
+    H.close()
