@@ -49,6 +49,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    int64_t opt_chol_downdate = 1;   // Cauchy search: rank-one downdate of the factor per breakpoint (0: downdate the Gram matrix and refactor)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
@@ -721,6 +722,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
+    if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }
@@ -1405,10 +1407,21 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
         if (index > 0 && mA > 0) {
-            hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
-                               (const CgState*)c.d_state);
-            if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
-            else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+            if (g_ctx.opt_chol_downdate) {
+                // add_active!: one more fixed variable = rank-one downdate of chol(A_free A_free'), O(mA^2)
+                if (mA <= 64)
+                    hipLaunchKernelGGL(chol_downdate_small_kernel, dim3(1), dim3(64), 0, s, P->Lr, (const double*)P->Ad, P->ldA, mA, P->info,
+                                       (const CgState*)c.d_state);
+                else
+                    hipLaunchKernelGGL(chol_downdate_kernel, dim3(1), dim3(CG_T), (size_t)mA * sizeof(double), s, P->Lr, (const double*)P->Ad,
+                                       P->ldA, mA, P->info, (const CgState*)c.d_state);
+            } else {
+                // refactor from the downdated Gram matrix, O(mA^3)
+                hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
+                                   (const CgState*)c.d_state);
+                if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+                else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+            }
         }
         BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632
         BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, -1));           // Hd = H*d    :609 / :633

@@ -1340,6 +1340,82 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
     if (tid == 0 && (s_bad != 0 || gate == nullptr)) info[0] = s_bad;   // gated (in-loop) calls only ever raise the flag
 }
 
+// Rank-one Cholesky DOWNDATE: L L' <- L L' - a a' with a = column `ind` (state->status) of A — what add_active! does to
+// A_free A_free' when one more variable becomes fixed.  O(m^2) instead of refactoring (O(m^3)); hyperbolic rotations in
+// the reciprocal-diagonal form: s = a_k / l_kk, c = sqrt(1 - s^2), l_kk <- c l_kk, l_ik <- (l_ik - s a_i)/c,
+// a_i <- c a_i - s l_ik.  m <= 64: one wave, row i of L in lane i's registers, 64 unrolled steps of two v_readlane
+// broadcasts + one rsqrt.  A non-positive 1 - s^2 (the downdated matrix is no longer positive definite) raises info.
+__global__ __launch_bounds__(64) void chol_downdate_small_kernel(double* __restrict__ L, const double* __restrict__ A, int64_t ldA, int m,
+                                                                 int* info, const CgState* st) {
+    if (st->done) return;
+    const int ind = st->status;
+    if (ind < 0) return;
+    const int lane = threadIdx.x;
+    double row[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) row[k] = (lane < m && k <= lane && k < m) ? L[lane + (int64_t)k * m] : 0.0;
+    double dinv = (lane < m) ? L[(int64_t)m * m + lane] : 0.0;
+    double a = (lane < m) ? A[(int64_t)lane * ldA + ind] : 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        if (k < m) {
+            const double ak = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), k), __builtin_amdgcn_readlane(__double2loint(a), k));
+            const double dk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dinv), k),
+                                               __builtin_amdgcn_readlane(__double2loint(dinv), k));
+            const double sn = ak * dk;
+            const double t = fma(-sn, sn, 1.0);
+            if (!(t > 0.0) && bad == 0) bad = k + 1;
+            const double rc = rsqrt(t);          // 1/c
+            const double c = t * rc;
+            if (lane == k) { row[k] = row[k] * c; dinv = dinv * rc; }
+            else if (lane > k) {
+                const double lik = (row[k] - sn * a) * rc;
+                a = fma(c, a, -sn * lik);
+                row[k] = lik;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+        if (lane < m && k <= lane && k < m) L[lane + (int64_t)k * m] = row[k];
+    if (lane < m) L[(int64_t)m * m + lane] = dinv;
+    if (lane == 0 && bad != 0) info[0] = bad;
+}
+
+// The same for any m: one workgroup, L in global memory (column k is contiguous), a in LDS.
+__global__ __launch_bounds__(CG_T) void chol_downdate_kernel(double* __restrict__ L, const double* __restrict__ A, int64_t ldA, int m,
+                                                             int* info, const CgState* st) {
+    if (st->done) return;
+    const int ind = st->status;
+    if (ind < 0) return;
+    extern __shared__ __attribute__((aligned(16))) double a_sh[];      // m doubles
+    __shared__ double s_c, s_s, s_rc;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < m; i += CG_T) a_sh[i] = A[(int64_t)i * ldA + ind];
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        double* colk = L + (int64_t)k * m;
+        if (tid == 0) {
+            const double lkk = colk[k];
+            const double sn = a_sh[k] / lkk;
+            const double t = fma(-sn, sn, 1.0);
+            if (!(t > 0.0) && info[0] == 0) info[0] = k + 1;
+            const double c = sqrt(t);
+            colk[k] = c * lkk;
+            s_c = c; s_s = sn; s_rc = 1.0 / c;
+        }
+        __syncthreads();
+        const double c = s_c, sn = s_s, rc = s_rc;
+        for (int i = k + 1 + tid; i < m; i += CG_T) {
+            const double lik = (colk[i] - sn * a_sh[i]) * rc;
+            a_sh[i] = fma(c, a_sh[i], -sn * lik);
+            colk[i] = lik;
+        }
+        __syncthreads();
+    }
+}
+
 // tw <- L' \ (L \ tw) for m <= 64 (reduced form).  256 threads stage L into an LDS tile (all loads in flight at once,
 // row stride 65: conflict-free both row- and column-wise); wave 0 then runs the 2 x m dependent steps
 // (readlane + LDS read + fma) with the reciprocal diagonal from chol_small_kernel.

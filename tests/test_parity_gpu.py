@@ -575,9 +575,18 @@ def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
 
 
 # ----------------------------------------------------------------------------- Cauchy step on the device (f-3)
+@pytest.fixture(params=[1, 0], ids=["factor_downdate", "gram_downdate_refactor"])
+def chol_downdate(request, bh):
+    """Per breakpoint: rank-one downdate of chol(A_free A_free') (default) or downdate of the Gram matrix + refactorisation."""
+    bh._lib.lib().bh_set_option(b"chol_downdate", request.param)
+    yield request.param
+    bh._lib.lib().bh_set_option(b"chol_downdate", 1)
+
+
 @pytest.mark.parametrize("d,n,mA,nact,delta_scale,seed", [(80, 30, 0, 4, 0.5, 1), (300, 120, 3, 10, 1.0, 2), (500, 200, 0, 0, 5.0, 3),
-                                                          (400, 96, 8, 6, 0.2, 4), (2000, 512, 4, 40, 2.0, 5), (60, 17, 1, 2, 1.0, 6)])
-def test_cauchy_step_parity(bh, d, n, mA, nact, delta_scale, seed):
+                                                          (400, 96, 8, 6, 0.2, 4), (2000, 512, 4, 40, 2.0, 5), (60, 17, 1, 2, 1.0, 6),
+                                                          (900, 300, 70, 12, 1.0, 7), (1500, 400, 64, 30, 3.0, 8)])
+def test_cauchy_step_parity(bh, chol_downdate, d, n, mA, nact, delta_scale, seed):
     """cauchy_step (src/basic_tralcnlss.jl:574-639) incl. next_breakpoint and the active-set growth, against the oracle:
     same breakpoints, same final active set, same step."""
     rng = np.random.default_rng(seed)
