@@ -119,8 +119,8 @@ struct RsConfig { int T, CPT, R, blocks_per_cu; };
 const RsConfig kRsConfigs[] = {
     {64, 1, 8, 8},     // 0: nchunks <= 64    (n <= 128)
     {256, 1, 8, 4},    // 1: nchunks <= 256   (n <= 512)
-    {256, 2, 8, 4},    // 2: nchunks <= 512   (n <= 1024)
-    {256, 4, 4, 4},    // 3: nchunks <= 1024  (n <= 2048)
+    {256, 2, 8, 2},    // 2: nchunks <= 512   (n <= 1024)   2 WGs/CU measured best (6.5 vs 6.0 TB/s at 4)
+    {256, 4, 4, 2},    // 3: nchunks <= 1024  (n <= 2048)   2 WGs/CU measured best (6.6 vs 6.0 TB/s at 4)
     {256, 8, 4, 1},    // 4: nchunks <= 2048  (n <= 4096)   variant 0 (measured best: 1 WG/CU, 128 KiB in flight)
     {512, 8, 2, 1},    // 5: nchunks <= 4096  (n <= 8192)
     {512, 4, 4, 1},    // 6: nchunks <= 2048  variant 1
