@@ -49,6 +49,7 @@ struct Ctx {
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    int64_t opt_chol_blocked = 1;    // mA > 64: blocked potrf/trsm/syrk chain (0: one-workgroup right-looking kernel)
     int64_t opt_chol_downdate = 1;   // Cauchy search: rank-one downdate of the factor per breakpoint (0: downdate the Gram matrix and refactor)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
@@ -544,6 +545,42 @@ int32_t ensure_reduced_buffers(bh_proj* P) {
     return BH_OK;
 }
 
+// Lr = chol(M) (lower, column-major mA x mA).  mA <= 64: one launch of the register-panel kernel (+ reciprocal diagonal
+// after the matrix for trsv_small_kernel).  Larger: blocked right-looking — per 64-column panel potrf on the diagonal
+// block, trsm for the rows below it, syrk for the trailing matrix (3 launches per panel; 1.6 ms -> ~0.3 ms at mA = 256).
+int32_t launch_chol(bh_proj* P, const CgState* gate) {
+    const int mA = (int)P->mA;
+    hipStream_t s = g_ctx.stream;
+    if (mA <= 64) {
+        hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->M, (int64_t)mA, P->Lr, (int64_t)mA, mA,
+                           P->Lr + (int64_t)mA * mA, P->info, 0, gate == nullptr ? 1 : 0, gate);
+        BH_HIP(hipGetLastError());
+        return BH_OK;
+    }
+    if (!g_ctx.opt_chol_blocked) {
+        hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, s, (const double*)P->M, P->Lr, mA, P->info, gate);
+        BH_HIP(hipGetLastError());
+        return BH_OK;
+    }
+    double* dinv = P->Lr + (int64_t)mA * mA;      // scratch for the current panel's reciprocal diagonal (mA extra doubles)
+    hipLaunchKernelGGL(copy_lower_kernel, dim3(std::min(1024, (mA * mA + 255) / 256)), dim3(256), 0, s, (const double*)P->M, P->Lr, mA,
+                       P->info, gate);
+    for (int k0 = 0; k0 < mA; k0 += 64) {
+        const int nb = std::min(64, mA - k0);
+        double* blk = P->Lr + k0 + (int64_t)k0 * mA;
+        hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)blk, (int64_t)mA, blk, (int64_t)mA, nb, dinv, P->info,
+                           k0, 0, gate);
+        const int rem = mA - k0 - nb;
+        if (rem > 0) {
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3((rem + 255) / 256), dim3(256), 0, s, P->Lr, mA, k0, nb, (const double*)dinv, gate);
+            const int nt = (rem + 15) / 16;
+            hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, s, P->Lr, mA, k0, nb, gate);
+        }
+    }
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
 // M = A_free A_free' from the device-side mask, then Lr = chol(M).  `gate`: skip when gate->done (in-loop use).
 int32_t launch_reduced_factor(bh_proj* P, bool use_mask, const CgState* gate) {
     const int mA = (int)P->mA;
@@ -558,9 +595,7 @@ int32_t launch_reduced_factor(bh_proj* P, bool use_mask, const CgState* gate) {
         hipLaunchKernelGGL(gram_free_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, g_ctx.stream, P->Ad, P->ldA, mA,
                            use_mask ? P->fixrank : (const int*)nullptr, P->M);
     }
-    if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
-    else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, (const double*)P->M, P->Lr, mA, P->info, gate);
-    BH_HIP(hipGetLastError());
+    BH_TRY(launch_chol(P, gate));
     return BH_OK;
 }
 
@@ -723,6 +758,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }
@@ -1419,8 +1455,7 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
                 // refactor from the downdated Gram matrix, O(mA^3)
                 hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
                                    (const CgState*)c.d_state);
-                if (mA <= 64) hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
-                else hipLaunchKernelGGL(chol_lower_kernel, dim3(1), dim3(CG_T), 0, s, (const double*)P->M, P->Lr, mA, P->info, (const CgState*)c.d_state);
+                BH_TRY(launch_chol(P, (const CgState*)c.d_state));
             }
         }
         BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632

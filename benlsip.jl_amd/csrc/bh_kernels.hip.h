@@ -1283,7 +1283,11 @@ __global__ __launch_bounds__(CG_T) void chol_lower_kernel(const double* __restri
 // applies the rank-one update to its panel.  (History: fully unrolled one-wave register version 100 us, instruction-fetch
 // bound; one-wave LDS loops 66-170 us, latency bound.)  Writes L (lower, column-major m x m) and the reciprocal diagonal
 // dinv[m] right after the matrix (dst + m*m), which turns the substitutions' divisions into multiplications.
-__global__ __launch_bounds__(256) void chol_small_kernel(const double* __restrict__ Msrc, double* __restrict__ M, int m, int* info,
+//   Strided form: src/dst are the top-left corners of an nb x nb (nb <= 64) block inside matrices with leading dimensions
+//   ld_src / ld_dst (in-place allowed); dinv_out receives the reciprocal diagonal; pivot failures are reported as
+//   info_base + column + 1.  reset_info: write 0 on success (stand-alone use) — blocked/in-loop callers only ever raise it.
+__global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int64_t ld_src, double* M, int64_t ld_dst, int m,
+                                                         double* dinv_out, int* info, int info_base, int reset_info,
                                                          const CgState* gate) {
     if (gate != nullptr && gate->done) return;
     __shared__ double colbuf[2][64];
@@ -1293,7 +1297,7 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int k = 16 * wave + c;
-        a[c] = (lane < m && k < m && k <= lane) ? Msrc[lane + (int64_t)k * m] : 0.0;
+        a[c] = (lane < m && k < m && k <= lane) ? Msrc[lane + (int64_t)k * ld_src] : 0.0;
     }
     if (tid == 0) s_bad = 0;
     double dinv_mine = 0.0;
@@ -1333,11 +1337,64 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* __restric
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int k = 16 * wave + c;
-        if (lane < m && k < m && k <= lane) M[lane + (int64_t)k * m] = a[c];
+        if (lane < m && k < m && k <= lane) M[lane + (int64_t)k * ld_dst] = a[c];
     }
-    if (lane < m && wave == (lane >> 4)) M[(int64_t)m * m + lane] = dinv_mine;
+    if (dinv_out != nullptr && lane < m && wave == (lane >> 4)) dinv_out[lane] = dinv_mine;
     __syncthreads();
-    if (tid == 0 && (s_bad != 0 || gate == nullptr)) info[0] = s_bad;   // gated (in-loop) calls only ever raise the flag
+    if (tid == 0) {
+        if (s_bad != 0) info[0] = info_base + s_bad;
+        else if (reset_info) info[0] = 0;
+    }
+}
+
+// ---- blocked Cholesky for m > 64: potrf (chol_small_kernel on the 64 x 64 diagonal block) / trsm / syrk per panel ------
+// Copy the lower triangle (gate-aware) so that the factorisation can run in place on dst.
+__global__ __launch_bounds__(256) void copy_lower_kernel(const double* __restrict__ src, double* __restrict__ dst, int m, int* info,
+                                                         const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    const int64_t total = (int64_t)m * m;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % m), k = (int)(e / m);
+        if (i >= k) dst[e] = src[e];
+    }
+    if (gate == nullptr && blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0;
+}
+
+// L21 <- A21 L11^{-T}: rows [r0, m) of the panel [k0, k0+nb).  One thread per row; L11 (lower, nb x nb) and its reciprocal
+// diagonal in LDS; column j of the row is finished before column j+1 (own earlier columns are re-read from global memory).
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ M, int m, int k0, int nb, const double* __restrict__ dinv,
+                                                        const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    __shared__ double l11[64 * 65];
+    __shared__ double di[64];
+    for (int e = threadIdx.x; e < nb * nb; e += 256) {
+        const int i = e % nb, k = e / nb;
+        l11[i * 65 + k] = (i >= k) ? M[(k0 + i) + (int64_t)(k0 + k) * m] : 0.0;
+    }
+    if (threadIdx.x < nb) di[threadIdx.x] = dinv[threadIdx.x];
+    __syncthreads();
+    const int r = k0 + nb + blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    for (int j = 0; j < nb; ++j) {
+        double acc = M[r + (int64_t)(k0 + j) * m];
+#pragma unroll 8
+        for (int c = 0; c < j; ++c) acc = fma(-M[r + (int64_t)(k0 + c) * m], l11[j * 65 + c], acc);
+        M[r + (int64_t)(k0 + j) * m] = acc * di[j];
+    }
+}
+
+// A22 <- A22 - L21 L21' (lower triangle only): 16 x 16 thread tiles, each thread one element, nb-long dot product of two
+// rows of the panel (column-major: consecutive threads along i read consecutive addresses).
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ M, int m, int k0, int nb, const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    const int base = k0 + nb;
+    const int i = base + blockIdx.x * 16 + (threadIdx.x & 15);
+    const int k = base + blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (blockIdx.y > blockIdx.x || i >= m || k >= m || i < k) return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < nb; ++c) acc = fma(M[i + (int64_t)(k0 + c) * m], M[k + (int64_t)(k0 + c) * m], acc);
+    M[i + (int64_t)k * m] -= acc;
 }
 
 // Rank-one Cholesky DOWNDATE: L L' <- L L' - a a' with a = column `ind` (state->status) of A — what add_active! does to
