@@ -88,3 +88,20 @@ def test_graft_entry_build_compiles():
     ge.build()
     import benlsip_jl_amd as bh
     assert os.path.exists(bh.library_path())
+
+
+def test_options_and_argument_checks_without_gpu():
+    """Entry points that need no device validate their arguments and report through the error-code convention."""
+    import ctypes as C
+    import benlsip_jl_amd as bh
+    lib = bh.load()
+    assert lib.bh_set_option(b"pcg_batch", 4) == 0
+    assert lib.bh_set_option(b"no_such_option", 1) == -1 and b"no_such_option" in lib.bh_last_error_detail()
+    assert lib.bh_set_option(None, 1) == -1
+    h = C.c_void_p()
+    assert lib.bh_hess_create(C.byref(h), None, 4, 3, 4, None, 0, 1, 1.0) == -2          # BH_ERR_NOT_INIT before bh_init
+    assert lib.bh_hess_destroy(None) == 0 and lib.bh_proj_destroy(None) == 0          # destroying NULL is a no-op
+    r, n = C.c_int32(-1), C.c_int32(-1)
+    assert lib.bh_comm_info(C.byref(r), C.byref(n)) == 0 and (r.value, n.value) == (0, 1)
+    for code in range(0, -9, -1):
+        assert len(lib.bh_strerror(code)) > 0
