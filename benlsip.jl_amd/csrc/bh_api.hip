@@ -129,6 +129,9 @@ const RsConfig kRsConfigs[] = {
     {1024, 2, 4, 1},   // 8: nchunks <= 2048  variant 3
     {512, 4, 2, 1},    // 9: nchunks <= 2048  variant 4
     {256, 8, 4, 1},    // 10: nchunks <= 2048 variant 5 = variant 0 WITHOUT non-temporal loads of J (A/B: nt = +10 %)
+    {256, 8, 4, 2},    // 11: variant 6 = one register buffer (no prefetch), 2 WGs/CU
+    {256, 8, 3, 1},    // 12: variant 7 = R = 3 with prefetch
+    {256, 8, 6, 1},    // 13: variant 8 = R = 6, one register buffer
 };
 constexpr int64_t kMaxChunks = 4096;
 
@@ -144,18 +147,21 @@ int pick_config(int nchunks) {
             case 3: return 8;
             case 4: return 9;
             case 5: return 10;
+            case 6: return 11;
+            case 7: return 12;
+            case 8: return 13;
             default: return 4;
         }
     }
     return 5;
 }
 
-template <int T, int CPT, int R, int NT = 1>
+template <int T, int CPT, int R, int NT = 1, int PF = 1>
 void launch_rs_mode(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
     switch (mode) {
-        case MODE_JV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JV, NT>), dim3(grid), dim3(T), 0, s, a); break;
-        case MODE_JTV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JTV, NT>), dim3(grid), dim3(T), 0, s, a); break;
-        default: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, NT>), dim3(grid), dim3(T), 0, s, a); break;
+        case MODE_JV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JV, NT, PF>), dim3(grid), dim3(T), 0, s, a); break;
+        case MODE_JTV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JTV, NT, PF>), dim3(grid), dim3(T), 0, s, a); break;
+        default: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, NT, PF>), dim3(grid), dim3(T), 0, s, a); break;
     }
 }
 
@@ -171,6 +177,9 @@ void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipS
         case 7: launch_rs_mode<256, 8, 2>(mode, a, grid, s); break;
         case 8: launch_rs_mode<1024, 2, 4>(mode, a, grid, s); break;
         case 10: launch_rs_mode<256, 8, 4, 0>(mode, a, grid, s); break;
+        case 11: launch_rs_mode<256, 8, 4, 1, 0>(mode, a, grid, s); break;
+        case 12: launch_rs_mode<256, 8, 3, 1, 1>(mode, a, grid, s); break;
+        case 13: launch_rs_mode<256, 8, 6, 1, 0>(mode, a, grid, s); break;
         default: launch_rs_mode<512, 4, 2>(mode, a, grid, s); break;
     }
 }

@@ -132,7 +132,9 @@ struct RowStreamArgs {
 };
 
 // NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
-template <int T, int CPT, int R, int MODE, int NT = 1>
+// PF: 1 = issue the next row group's loads before reducing the current one (two register buffers); 0 = one buffer, latency
+// hidden by several co-resident workgroups instead.
+template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1>
 __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     if (a.state != nullptr && a.state->done) return;
     constexpr int NW = T / 64;
@@ -244,7 +246,12 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     };
 
     int64_t g = blockIdx.x;
-    if (g < ngroups) {
+    if (!PF) {
+        for (; g < ngroups; g += G) {
+            load_group(A, g);
+            process(A, g);
+        }
+    } else if (g < ngroups) {
         load_group(A, g);
         while (true) {
             int64_t gn = g + G;
