@@ -1125,7 +1125,8 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     const int64_t n = H->n, n_pad = H->ld;
     const int64_t max_iter64 = 2 * (n - P->mA - P->nfix);   // src/basic_tralcnlss.jl:714
     if (max_iter64 < 0) return fail(BH_ERR_PRECONDITION, "n - mA - count(fixvars) < 0");
-    const int max_iter = (int)std::min<int64_t>(max_iter64, 0x7fffffff);
+    if (max_iter64 >= 0xfffff) return fail(BH_ERR_UNSUPPORTED, "2*(n - mA - count(fixvars)) exceeds the 20-bit iteration counters of the progress word");
+    const int max_iter = (int)max_iter64;
     CgWorkspace& c = g_ctx.cg;
     H->ev_pending.clear();
     hipStream_t s = g_ctx.stream;
@@ -1448,7 +1449,8 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     P->active_set = false;             // device mask is authoritative until adopt_mask below
     hipLaunchKernelGGL(cauchy_init_kernel, dim3(1), dim3(CG_T), 0, s, a);
     if (mA > 0) BH_TRY(launch_reduced_factor(P, true, nullptr));
-    const int max_pass = (int)std::min<int64_t>(n + 1, 0xfffff);
+    if (n + 1 >= 0xfffff) return fail(BH_ERR_UNSUPPORTED, "n exceeds the 20-bit pass counter of the progress word");
+    const int max_pass = (int)(n + 1);
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
         if (index > 0 && mA > 0) {
