@@ -222,6 +222,15 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 buf ^= 1;
             }
         }
+        if (MODE == MODE_JV && a.t_out != nullptr) {
+            // the R results of the group leave in ONE store instruction (lanes 0..R-1 of wave 0, R*8 contiguous bytes)
+            double mine = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (tid == r) mine = s[r];
+            const int64_t row = grp * R + tid;
+            if (tid < R && row < a.nrows) a.t_out[row] = a.accumulate ? a.t_out[row] + mine : mine;
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = grp * R + r;
@@ -230,7 +239,6 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 if (rv) {
                     const double wgt = (row < a.d_rows) ? 1.0 : a.mu;
                     sq_acc = fma(wgt * s[r], s[r], sq_acc);
-                    if (a.t_out != nullptr && tid == r) a.t_out[row] = a.accumulate ? a.t_out[row] + s[r] : s[r];
                 }
             } else {
                 double coef;
