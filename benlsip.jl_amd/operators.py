@@ -19,7 +19,7 @@ read like the reference's own tests (``test/structures.jl``).  ``julia/BEnlsipHI
 
 Everything numerical runs on the GPU; there is no CPU fallback.
 """
-import ctypes as C
+import ctypes as ct
 import enum
 import math
 
@@ -61,7 +61,7 @@ class AlHessian:
             raise ValueError("C must be q x n")
         q = C.shape[0]
         Cf = np.asfortranarray(C)
-        self._h = C_void()
+        self._h = _null_handle()
         check(lib.bh_hess_create(_byref(self._h), ptr(Jf) if d > 0 else None, d, n, max(d, 1),
                                  ptr(Cf) if q > 0 else None, q, max(q, 1), float(mu)), "bh_hess_create")
         self.d, self.n, self.q = d, n, q
@@ -72,7 +72,7 @@ class AlHessian:
         """Benchmark instance generated in HBM; see ``bh_hess_create_synthetic``."""
         lib = _lib.lib()
         self = cls.__new__(cls)
-        self._h = C_void()
+        self._h = _null_handle()
         d_total = d if d_total is None else d_total
         cs = None if colscale is None else as_f64(colscale, n)
         check(lib.bh_hess_create_synthetic(_byref(self._h), d, n, row0, d_total, seed, ptr(cs), float(mu)),
@@ -116,7 +116,7 @@ class AlHessian:
 
     def stats(self):
         st = _lib.bh_stats_t()
-        check(_lib.lib().bh_stats(self._h, C.byref(st)), "bh_stats")
+        check(_lib.lib().bh_stats(self._h, ct.byref(st)), "bh_stats")
         return {name: getattr(st, name) for name, _ in st._fields_}
 
     def reset_stats(self):
@@ -124,14 +124,14 @@ class AlHessian:
 
     def time_kernel(self, kind, reps=20):
         """Average hipEvent milliseconds of one launch: kind 0 = fused J'(Jp), 1 = J v, 2 = J'u."""
-        ms = C.c_double(0.0)
-        check(_lib.lib().bh_time_kernel(self._h, kind, reps, C.byref(ms)), "bh_time_kernel")
+        ms = ct.c_double(0.0)
+        check(_lib.lib().bh_time_kernel(self._h, kind, reps, ct.byref(ms)), "bh_time_kernel")
         return ms.value
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().bh_hess_destroy(self._h)
-            self._h = C_void()
+            self._h = _null_handle()
 
     def __del__(self):
         try:
@@ -140,12 +140,12 @@ class AlHessian:
             pass
 
 
-def C_void():
-    return C.c_void_p()
+def _null_handle():
+    return ct.c_void_p()
 
 
 def _byref(h):
-    return C.byref(h)
+    return ct.byref(h)
 
 
 def hmul(H, v):
@@ -159,8 +159,8 @@ def hmul(H, v):
 def vthv(H, v):
     """``vthv(H, v)`` — src/basic_tralcnlss.jl:92-96."""
     v = as_f64(v, H.n)
-    out = C.c_double(0.0)
-    check(_lib.lib().bh_vthv(H.handle, ptr(v), C.byref(out)), "bh_vthv")
+    out = ct.c_double(0.0)
+    check(_lib.lib().bh_vthv(H.handle, ptr(v), ct.byref(out)), "bh_vthv")
     return out.value
 
 
@@ -195,7 +195,7 @@ class MixedConstraints:
         self.xlow = np.full(n, -np.inf) if l is None else as_f64(l, n)
         self.xupp = np.full(n, np.inf) if u is None else as_f64(u, n)
         Af = np.asfortranarray(A)
-        self._h = C_void()
+        self._h = _null_handle()
         check(lib.bh_proj_create(_byref(self._h), ptr(Af) if mA > 0 else None, mA, n, max(mA, 1)), "bh_proj_create")
         self.mA, self.n = mA, n
         self._fixvars = np.zeros(n, dtype=bool) if fixed is None else np.asarray(fixed, dtype=bool).copy()
@@ -257,7 +257,7 @@ class MixedConstraints:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().bh_proj_destroy(self._h)
-            self._h = C_void()
+            self._h = _null_handle()
 
     def __del__(self):
         try:
@@ -302,8 +302,8 @@ def factor_to_boundary(p, w, w_l, w_u, atol=1e-10):
     p = as_f64(p)
     n = p.shape[0]
     w, w_l, w_u = as_f64(w, n), as_f64(w_l, n), as_f64(w_u, n)
-    out = C.c_double(0.0)
-    check(_lib.lib().bh_factor_to_boundary(ptr(p), ptr(w), ptr(w_l), ptr(w_u), n, float(atol), C.byref(out)),
+    out = ct.c_double(0.0)
+    check(_lib.lib().bh_factor_to_boundary(ptr(p), ptr(w), ptr(w_l), ptr(w_u), n, float(atol), ct.byref(out)),
           "bh_factor_to_boundary")
     return out.value
 
@@ -318,10 +318,10 @@ def projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, atol=SQRT_EPS, atol_f2b=
     g = as_f64(g_minor, n)
     wl, wu = as_f64(w_l, n), as_f64(w_u, n)
     w = np.empty(n)
-    status, iters, n_hmul = C.c_int32(-1), C.c_int32(0), C.c_int32(0)
+    status, iters, n_hmul = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0)
     trace = np.full((trace_cap, 4), np.nan) if trace_cap > 0 else None
     check(_lib.lib().bh_pcg(H.handle, lincons.handle, ptr(g), ptr(wl), ptr(wu), float(kappa2), float(atol), float(atol_f2b),
-                            ptr(w), C.byref(status), C.byref(iters), ptr(trace), trace_cap, C.byref(n_hmul)), "bh_pcg")
+                            ptr(w), ct.byref(status), ct.byref(iters), ptr(trace), trace_cap, ct.byref(n_hmul)), "bh_pcg")
     st = CGStatus(status.value)
     if full_output:
         info = {"iters": iters.value, "n_hmul": n_hmul.value,
@@ -333,9 +333,9 @@ def projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, atol=SQRT_EPS, atol_f2b=
 def linesearch(g_model, H, w, w_l, w_u, lincons):
     """``linesearch(g_model, H, w, w_l, w_u, fix_bounds)`` — src/basic_tralcnlss.jl:766-791 (``fix_bounds`` = lincons.fixvars)."""
     n = H.n
-    out = C.c_double(0.0)
+    out = ct.c_double(0.0)
     g, w, wl, wu = as_f64(g_model, n), as_f64(w, n), as_f64(w_l, n), as_f64(w_u, n)
-    check(_lib.lib().bh_linesearch(H.handle, lincons.handle, ptr(g), ptr(w), ptr(wl), ptr(wu), C.byref(out)), "bh_linesearch")
+    check(_lib.lib().bh_linesearch(H.handle, lincons.handle, ptr(g), ptr(w), ptr(wl), ptr(wu), ct.byref(out)), "bh_linesearch")
     return out.value
 
 
@@ -345,10 +345,10 @@ def minor_iterate(x, s, g_model, H, lincons, delta, kappa2, atol=SQRT_EPS, atol_
     n = H.n
     x, s, g = as_f64(x, n), as_f64(s, n), as_f64(g_model, n)
     w = np.empty(n)
-    status, iters, n_hmul, alpha = C.c_int32(-1), C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+    status, iters, n_hmul, alpha = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0), ct.c_double(0.0)
     check(_lib.lib().bh_minor_iterate(H.handle, lincons.handle, ptr(x), ptr(s), ptr(g), ptr(lincons.xlow), ptr(lincons.xupp),
-                                      float(delta), float(kappa2), float(atol), float(atol_f2b), ptr(w), C.byref(status),
-                                      C.byref(iters), C.byref(n_hmul), C.byref(alpha)), "bh_minor_iterate")
+                                      float(delta), float(kappa2), float(atol), float(atol_f2b), ptr(w), ct.byref(status),
+                                      ct.byref(iters), ct.byref(n_hmul), ct.byref(alpha)), "bh_minor_iterate")
     st = CGStatus(status.value)
     if full_output:
         return w, st, {"iters": iters.value, "n_hmul": n_hmul.value, "alpha": alpha.value}
@@ -364,10 +364,10 @@ def cauchy_step(x, g, H, lincons, delta, full_output=False):
     s = np.empty(n)
     nwords = (n + 63) // 64
     chunks = np.zeros(nwords, dtype=np.uint64)
-    nbp, nh = C.c_int32(0), C.c_int32(0)
+    nbp, nh = ct.c_int32(0), ct.c_int32(0)
     lincons._sync()
     check(_lib.lib().bh_cauchy_step(H.handle, lincons._h, ptr(x), ptr(g), ptr(lincons.xlow), ptr(lincons.xupp), float(delta), ptr(s),
-                                    ptr(chunks), C.byref(nbp), C.byref(nh)), "bh_cauchy_step")
+                                    ptr(chunks), ct.byref(nbp), ct.byref(nh)), "bh_cauchy_step")
     bits = np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].astype(bool)
     lincons._fixvars = bits
     lincons._chol = None
@@ -399,7 +399,7 @@ class DeviceVector:
 
     def __init__(self, n, host=None):
         self.n = int(n)
-        self._p = C_void()
+        self._p = _null_handle()
         check(_lib.lib().bh_dev_alloc(_byref(self._p), 8 * max(self.n, 1)), "bh_dev_alloc")
         if host is not None:
             self.upload(host)
@@ -420,7 +420,7 @@ class DeviceVector:
     def close(self):
         if self._p.value:
             _lib.lib().bh_dev_free(self._p)
-            self._p = C_void()
+            self._p = _null_handle()
 
     def __del__(self):
         try:
@@ -431,8 +431,8 @@ class DeviceVector:
 
 def projected_cg_dev(g_dev, H, wl_dev, wu_dev, lincons, kappa2, w_out_dev, atol=SQRT_EPS, atol_f2b=1e-10):
     """``bh_pcg_dev``: all vectors already in HBM (what bench.py times).  Returns (status, iters, n_hmul)."""
-    status, iters, n_hmul = C.c_int32(-1), C.c_int32(0), C.c_int32(0)
+    status, iters, n_hmul = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0)
     check(_lib.lib().bh_pcg_dev(H.handle, lincons.handle, g_dev.ptr, wl_dev.ptr, wu_dev.ptr, float(kappa2), float(atol),
-                                float(atol_f2b), w_out_dev.ptr, C.byref(status), C.byref(iters), None, 0, C.byref(n_hmul)),
+                                float(atol_f2b), w_out_dev.ptr, ct.byref(status), ct.byref(iters), None, 0, ct.byref(n_hmul)),
           "bh_pcg_dev")
     return CGStatus(status.value), iters.value, n_hmul.value
