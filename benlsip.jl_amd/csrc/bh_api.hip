@@ -457,6 +457,15 @@ int32_t alloc_hess_common(bh_hess* H) {
 
 // Upload a column-major host matrix (rows x cols, leading dimension ldh) into rows [row0, row0+rows) of a
 // row-major padded device image with leading dimension ldd.
+// The same from a column-major matrix that already lives in HBM (a device-side jac_res): transpose only, no PCIe.
+int32_t transpose_from_device(const double* src_dev, int64_t rows, int64_t cols, int64_t lds, double* dst_image, int64_t row0, int64_t ldd) {
+    if (rows == 0) return BH_OK;
+    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((ldd + 31) / 32));
+    hipLaunchKernelGGL(transpose_cm_to_rm_kernel, grid, dim3(256), 0, g_ctx.stream, src_dev, lds, rows, cols, dst_image + row0 * ldd, ldd);
+    BH_HIP(hipGetLastError());
+    return BH_OK;
+}
+
 int32_t upload_transposed(const double* host, int64_t rows, int64_t cols, int64_t ldh, double* dst_image, int64_t row0,
                           int64_t ldd) {
     if (rows == 0) return BH_OK;
@@ -853,6 +862,25 @@ int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int
     if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     BH_TRY(sync_flush());
+    *out = H;
+    return BH_OK;
+}
+
+int32_t bh_hess_create_dev(bh_hess** out, const double* J_dev, int64_t d, int64_t n, int64_t ldJ, const double* C, int64_t q,
+                           int64_t ldC, double mu) {
+    BH_REQUIRE_INIT();
+    if (!out) return fail(BH_ERR_INVALID_ARG, "NULL out");
+    *out = nullptr;
+    if (d < 0 || n < 1 || q < 0) return fail(BH_ERR_INVALID_ARG, "negative dimension");
+    if (d > 0 && (!J_dev || ldJ < d)) return fail(BH_ERR_INVALID_ARG, "J NULL or ldJ < d");
+    if (q > 0 && (!C || ldC < q)) return fail(BH_ERR_INVALID_ARG, "C NULL or ldC < q");
+    bh_hess* H = new bh_hess();
+    H->d = d; H->n = n; H->q = q; H->mu = mu;
+    int32_t rc = alloc_hess_common(H);
+    if (rc == BH_OK) rc = transpose_from_device(J_dev, d, n, ldJ, H->Jd, 0, H->ld);
+    if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
+    if (rc == BH_OK && hipStreamSynchronize(g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "bh_hess_create_dev: synchronize");
+    if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     *out = H;
     return BH_OK;
 }

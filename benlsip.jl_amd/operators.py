@@ -68,6 +68,22 @@ class AlHessian:
         self._mu = float(mu)
 
     @classmethod
+    def from_device(cls, J_dev_ptr, d, n, ldJ=None, C=None, mu=0.0):
+        """J already in HBM (column-major d x n at device address ``J_dev_ptr``, e.g. ``tensor.data_ptr()`` or a
+        ``DeviceVector.ptr``): only the device transpose runs (``bh_hess_create_dev``)."""
+        lib = _lib.lib()
+        self = cls.__new__(cls)
+        self._h = _null_handle()
+        Cm = np.zeros((0, n)) if C is None else np.asarray(C, dtype=np.float64)
+        q = Cm.shape[0]
+        Cf = np.asfortranarray(Cm)
+        check(lib.bh_hess_create_dev(_byref(self._h), J_dev_ptr, d, n, d if ldJ is None else ldJ, ptr(Cf) if q > 0 else None, q,
+                                     max(q, 1), float(mu)), "bh_hess_create_dev")
+        self.d, self.n, self.q = d, n, q
+        self._mu = float(mu)
+        return self
+
+    @classmethod
     def synthetic(cls, d, n, row0=0, d_total=None, seed=1, colscale=None, mu=10.0):
         """Benchmark instance generated in HBM; see ``bh_hess_create_synthetic``."""
         lib = _lib.lib()

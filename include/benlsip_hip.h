@@ -101,6 +101,11 @@ int32_t bh_comm_info(int32_t* rank, int32_t* nranks);
  * NULL when q == 0; replicated on every rank) and lays them out for the kernels. */
 int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int64_t ldJ,
                        const double* C, int64_t q, int64_t ldC, double mu);
+/* The same for a Jacobian that already lives in HBM (a device-side jac_res): J_dev is a DEVICE pointer,
+ * column-major d x n with leading dimension ldJ; only the transpose into the kernels' layout happens (no PCIe traffic for J).
+ * C (q x n) stays a host pointer. */
+int32_t bh_hess_create_dev(bh_hess** out, const double* J_dev, int64_t d, int64_t n, int64_t ldJ,
+                           const double* C, int64_t q, int64_t ldC, double mu);
 /* Benchmark constructor: rows [row0, row0+d) of the d_total x n synthetic Jacobian of SURVEY.md §8(d),
  * element (i,j) = u(seed, i + j*d_total)/sqrt(d_total) * (colscale ? colscale[j] : 1), generated in HBM. */
 int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t row0, int64_t d_total,

@@ -722,3 +722,18 @@ def test_pcg_config3_full_size_against_oracle(bh):
         assert relnorm(w, w_ref) <= 1e-9, relnorm(w, w_ref)
         np.testing.assert_allclose(info["trace"], np.array(tr.rows), rtol=1e-9)
     H.close()
+
+
+def test_hessian_from_device_resident_jacobian(bh):
+    """bh_hess_create_dev (f-4: a device-side jac_res hands over J in HBM): same image as the host upload."""
+    rng = np.random.default_rng(9)
+    d, n, q = 300, 130, 2
+    J, C = rng.standard_normal((d, n)), rng.standard_normal((q, n))
+    Jf = np.asfortranarray(J)
+    buf = bh.DeviceVector(d * n, Jf.ravel(order="F"))
+    H_dev = bh.AlHessian.from_device(buf.ptr, d, n, C=C, mu=3.0)
+    H_host = bh.AlHessian(J, C, 3.0)
+    v = rng.standard_normal(n)
+    assert np.array_equal(H_dev * v, H_host * v)
+    assert np.array_equal(H_dev.jv(v), H_host.jv(v))
+    assert bh.vthv(H_dev, v) == bh.vthv(H_host, v)
