@@ -85,10 +85,17 @@ function handle(lincons::BEnlsip.MixedConstraints{Float64})
     # cholesky_aug_aat has uplo == 'L' (factors = L), the initial cholesky(A*A') has uplo == 'U' (SURVEY.md §0.3-15).
     mA, n = size(lincons.lineq)
     mpp = mA + count(lincons.fixvars)
-    L = lincons.chol.uplo == 'L' ? lincons.chol.factors : Matrix(lincons.chol.L)
-    check(ccall((:bh_proj_set_active, libbh), Int32,
-                (Ptr{Cvoid}, Ptr{UInt64}, Int64, Ptr{Float64}, Int64, Int64),
-                h.ptr, lincons.fixvars.chunks, n, L, mpp, max(stride(L, 2), 1)), "bh_proj_set_active")
+    if SKIP_HOST_FACTOR[]
+        # reduced form: the factor argument is optional (lincons.chol may be stale, see skip_host_factor!)
+        check(ccall((:bh_proj_set_active, libbh), Int32,
+                    (Ptr{Cvoid}, Ptr{UInt64}, Int64, Ptr{Float64}, Int64, Int64),
+                    h.ptr, lincons.fixvars.chunks, n, C_NULL, mpp, max(mpp, 1)), "bh_proj_set_active")
+    else
+        L = lincons.chol.uplo == 'L' ? lincons.chol.factors : Matrix(lincons.chol.L)
+        check(ccall((:bh_proj_set_active, libbh), Int32,
+                    (Ptr{Cvoid}, Ptr{UInt64}, Int64, Ptr{Float64}, Int64, Int64),
+                    h.ptr, lincons.fixvars.chunks, n, L, mpp, max(stride(L, 2), 1)), "bh_proj_set_active")
+    end
     return h.ptr
 end
 
@@ -146,6 +153,24 @@ function BEnlsip.cauchy_step(x::Vector{Float64}, g::Vector{Float64}, H::BEnlsip.
     lincons.fixvars.chunks .= chunks
     BEnlsip.update_chol!(lincons, chol_aat)
     return s_c
+end
+
+# ---- optional: drop the host-side factor maintenance (SURVEY.md §8 f-1) ---------------------------------------------------
+# With the library's default reduced projection form the device factors A_free*A_free' (mA x mA) itself and never reads
+# lincons.chol.  The reference still rebuilds the augmented (mA+p) x (mA+p) factor from scratch in update_chol! after every
+# active-set change (active_bounds!, add_active! — src/polyhedral_constraints.jl:62-68,203-261): O(p^3) on the host, the
+# wall-clock bottleneck once H*p is fast.  Since every consumer of lincons.chol (projection!) is routed to the device, that
+# rebuild can be skipped.  Opt-in, because it changes what lincons.chol holds for any other user code:
+#     BEnlsipHIP.skip_host_factor!(true)
+const SKIP_HOST_FACTOR = Ref(false)
+skip_host_factor!(flag::Bool = true) = (SKIP_HOST_FACTOR[] = flag)
+
+function BEnlsip.update_chol!(lincons::BEnlsip.MixedConstraints{Float64}, chol_aat::Cholesky{Float64,Matrix{Float64}})
+    if SKIP_HOST_FACTOR[]
+        return                                        # the device rebuilds its own reduced factor in bh_proj_set_active
+    end
+    lincons.chol = BEnlsip.cholesky_aug_aat(lincons.lineq, lincons.fixvars, chol_aat)    # the reference's body (:66)
+    return
 end
 
 # ---- multi-GPU: one Julia process per GPU (e.g. MPI.jl / Distributed); rows of J and of r are sharded by the caller ----
