@@ -1,3 +1,5 @@
+"""Manual soak run (not collected by pytest): `python tests/soak_gpu.py` on the GPU box — 3200 fuzz cases against the C
+oracle, then 6000 repeated config-3 subproblems that must return bit-identical results."""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
