@@ -737,3 +737,35 @@ def test_hessian_from_device_resident_jacobian(bh):
     assert np.array_equal(H_dev * v, H_host * v)
     assert np.array_equal(H_dev.jv(v), H_host.jv(v))
     assert bh.vthv(H_dev, v) == bh.vthv(H_host, v)
+
+
+def test_inner_step_device_chain_against_oracle(bh, capsys):
+    """One whole `inner_step` (src/basic_tralcnlss.jl:394-460: Cauchy search, then minor iterates) with every hot-path and
+    "next"-row call on the device (bh_cauchy_step, bh_minor_iterate, bh_hmul_add, bh_project, bh_vthv) against the
+    all-CPU oracle on a config-2-shaped instance; prints both wall times."""
+    import time
+    d, n = 4096, 512
+    J = R.synthetic_J(d, n, seed=1)
+    inst = R.synthetic_box_vectors(d, n, fix_every=8)
+    A = np.zeros((0, n))
+    L0 = R.chol_lower(A @ A.T)
+    g = J.T @ inst.r0
+    delta = R.initial_tr(g)
+
+    def run(ops):
+        cons = R.make_mixed_constraints(A, L0, l=inst.x_l, u=inst.x_u)
+        H = ops.new_hessian(J, np.zeros((0, n)), 10.0)
+        log = []
+        t0 = time.perf_counter()
+        s, pred = R.inner_step(inst.x, g, H, L0, cons, delta, 50, 0.1, 0.1, ops=ops, log=log)
+        return s, pred, log, cons.fixvars.copy(), time.perf_counter() - t0
+
+    s_ref, pred_ref, log_ref, fix_ref, t_cpu = run(R.NumpyOps())
+    s, pred, log, fix, t_gpu = run(HipOpsDeviceAll(bh))
+    with capsys.disabled():
+        print("[inner_step d=%d n=%d] oracle (CPU) %.3f s, device chain %.3f s, %d minor iterates, %d active bounds"
+              % (d, n, t_cpu, t_gpu, len(log_ref), int(fix_ref.sum())))
+    assert [x[1] for x in log] == [x[1] for x in log_ref]          # same CG exit status in every minor iterate
+    assert np.array_equal(fix, fix_ref)                            # same final active set
+    assert relnorm(s, s_ref) <= 1e-6, relnorm(s, s_ref)
+    assert pred == pytest.approx(pred_ref, rel=1e-8)
