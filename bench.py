@@ -210,6 +210,20 @@ def main():
             "fused_ms": ms_f, "fused_gbs": st["bytes_per_hmul"] / ms_f / 1e6,
             "note": "back-to-back launches timed with hipEvents on the launch stream (bh_time_kernel), this rank's shard",
         }
+    if world == 1 and not args.no_extras and args.variant == "wc":
+        # steady-state CG iteration cost on the ill-conditioned variant (23 iterations per subproblem): outside the timed region
+        H.close()
+        H2, cons2, dv2, _ = setup_instance(bh, rank, world, 1)
+        run_steps(bh, H2, cons2, dv2, kappa2, 2)
+        barrier()
+        t1 = time.perf_counter()
+        st2, it2, nh2 = run_steps(bh, H2, cons2, dv2, kappa2, 5)
+        barrier()
+        el2 = (time.perf_counter() - t1) / 5
+        line["ic_variant"] = {"workload": "same instance with columns of J scaled by 10^(-3j/n)", "cg_status": st2.name,
+                              "hmul_per_subproblem": nh2, "ms_per_subproblem": 1e3 * el2, "ms_per_cg_iteration": 1e3 * el2 / max(nh2, 1),
+                              "subproblems_per_s": 1.0 / el2,
+                              "cg_iteration_gbs": st["bytes_per_hmul"] / (el2 / max(nh2, 1)) / 1e9}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(kind, kappa2, n_hmul)
     elif rank == 0:
