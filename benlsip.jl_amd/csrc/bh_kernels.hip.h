@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ M, 
         const int i = e % nb, k = e / nb;
         l11[i * 65 + k] = (i >= k) ? M[(k0 + i) + (int64_t)(k0 + k) * m] : 0.0;
     }
-    if (threadIdx.x < nb) di[threadIdx.x] = dinv[threadIdx.x];
+    if ((int)threadIdx.x < nb) di[threadIdx.x] = dinv[threadIdx.x];
     __syncthreads();
     const int r = k0 + nb + blockIdx.x * 256 + threadIdx.x;
     if (r >= m) return;
