@@ -769,3 +769,34 @@ def test_inner_step_device_chain_against_oracle(bh, capsys):
     assert np.array_equal(fix, fix_ref)                            # same final active set
     assert relnorm(s, s_ref) <= 1e-6, relnorm(s, s_ref)
     assert pred == pytest.approx(pred_ref, rel=1e-8)
+
+
+def test_interleaved_handles_share_the_workspace_safely(bh):
+    """Several AlHessian / MixedConstraints objects alive at once (the reference holds the old and the new Hessian across
+    an accepted step) and used alternately: the shared CG workspace and progress word must not leak state between them."""
+    rng = np.random.default_rng(123)
+    probs = []
+    for (d, n, mA, nfix) in [(120, 40, 0, 5), (300, 96, 2, 10), (90, 33, 0, 0), (500, 128, 4, 20)]:
+        J = rng.standard_normal((d, n)) / np.sqrt(d)
+        A = rng.standard_normal((mA, n))
+        fix = np.zeros(n, dtype=bool)
+        fix[rng.choice(n, nfix, replace=False)] = True
+        cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix if nfix else None, l=-np.ones(n), u=np.ones(n))
+        g = rng.standard_normal(n)
+        w_l, w_u = R.build_step_bounds(np.where(fix, 1.0, 0.0), cons_o, 0.5)
+        Ho = R.AlHessian(J, np.zeros((0, n)), 2.0)
+        ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+        probs.append(dict(H=bh.AlHessian(J, None, 2.0), cons=bh.MixedConstraints(A, cons_o.chol_L, fix), g=g, w_l=w_l, w_u=w_u,
+                          ref=ref, Ho=Ho, r=rng.standard_normal(n), cons_o=cons_o))
+    first = {}
+    for rnd in range(3):
+        for i in (0, 1, 2, 3, 2, 0, 3, 1):
+            p = probs[i]
+            w, st, info = bh.projected_cg(p["g"], p["H"], p["w_l"], p["w_u"], p["cons"], 0.1, full_output=True)
+            assert int(st) == int(p["ref"][1]) and info["iters"] == p["ref"][2]
+            assert relnorm(w, p["ref"][0]) <= 1e-8
+            if i in first:
+                assert np.array_equal(w, first[i])            # bit-identical every time, whatever ran in between
+            first[i] = w
+            assert relnorm(bh.projection(p["cons"], p["r"]), R.projection(p["cons_o"], p["r"])) <= 1e-10
+            assert relnorm(p["H"] * p["g"], R.hmul(p["Ho"], p["g"])) <= 1e-12
