@@ -800,3 +800,43 @@ def test_interleaved_handles_share_the_workspace_safely(bh):
             first[i] = w
             assert relnorm(bh.projection(p["cons"], p["r"]), R.projection(p["cons_o"], p["r"])) <= 1e-10
             assert relnorm(p["H"] * p["g"], R.hmul(p["Ho"], p["g"])) <= 1e-12
+
+
+def test_row_sharded_products_emulated_on_one_gpu(bh):
+    """SURVEY.md §8(e) on one device: G handles, one per row block (what each rank holds; C only with block 0), their
+    products summed in rank order (what the all-reduce does) — against the unsharded handle and the oracle, for H*v, J'u,
+    vthv and a whole projected_cg driven shard-wise."""
+    rng = np.random.default_rng(2024)
+    d, n, q, G = 1000, 192, 2, 4
+    J = R.synthetic_J(d, n, seed=7)
+    C = rng.standard_normal((q, n))
+    mu = 10.0
+    H_full, Ho = bh.AlHessian(J, C, mu), R.AlHessian(J, C, mu)
+    shards = []
+    for k in range(G):
+        lo, hi = bh.row_shard(d, k, G)
+        shards.append((lo, hi, bh.AlHessian(J[lo:hi], C if k == 0 else None, mu)))
+    v, u = rng.standard_normal(n), rng.standard_normal(d)
+
+    def sharded_hmul(_H, x):
+        z = np.zeros(n)
+        for lo, hi, Hk in shards:            # fixed rank order, like a ring/tree all-reduce result
+            z += Hk * x
+        return z
+    scale = np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(v)) + mu * np.abs(C).T @ (np.abs(C) @ np.abs(v)))
+    assert np.linalg.norm(sharded_hmul(None, v) - H_full * v) <= 1e-12 * scale
+    assert np.linalg.norm(sharded_hmul(None, v) - R.hmul(Ho, v)) <= 1e-12 * scale
+    jtu = sum(Hk.jtv(u[lo:hi]) for lo, hi, Hk in shards)
+    assert np.linalg.norm(jtu - J.T @ u) <= 1e-12 * matvec_scale(J.T, u)
+    assert sum(bh.vthv(Hk, v) for _, _, Hk in shards) == pytest.approx(R.vthv(Ho, v), rel=1e-12)
+    # the CG loop with shard-wise products (replicated n-vector work) reaches the same exit as the unsharded device run
+    inst = R.synthetic_box_vectors(d, n, fix_every=6)
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    g = J.T @ inst.r0
+    w_l, w_u = R.build_step_bounds(inst.x, cons_o, R.initial_tr(g))
+    w_sh, s_sh, it_sh = R.projected_cg(g, None, w_l, w_u, cons_o, 0.01, hmul_fn=sharded_hmul)
+    cons = bh.MixedConstraints(A, None, inst.fixvars)
+    w, st, info = bh.projected_cg(g, H_full, w_l, w_u, cons, 0.01, full_output=True)
+    assert int(st) == int(s_sh) and info["iters"] == it_sh
+    assert relnorm(w, w_sh) <= 1e-9
