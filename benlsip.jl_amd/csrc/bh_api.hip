@@ -1470,6 +1470,7 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     a.negg = c.r; a.d = c.p; a.Hd = c.Hp; a.s = c.w; a.dl = c.wl; a.du = c.wu;
     a.fixrank = P->fixrank; a.n = (int)n; a.n_pad = (int)H->ld; a.nmm = (int)(n - mA);
     a.delta = delta; a.atol = std::sqrt(2.220446049250313e-16);
+    a.box = (mA == 0) ? 1 : 0;
     c.tag = (c.tag + 1) & 0xffffu;
     if (c.tag == 0) c.tag = 1;
     a.mirror = c.d_mirror; a.tag = c.tag;
@@ -1497,7 +1498,7 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
                 BH_TRY(launch_chol(P, (const CgState*)c.d_state));
             }
         }
-        BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632
+        if (mA > 0) BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632  (box: kept in place)
         BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, -1));           // Hd = H*d    :609 / :633
         hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CG_T), 0, s, a);
         BH_HIP(hipGetLastError());

@@ -920,6 +920,7 @@ struct CauchyArgs {
     int* fixrank;
     int n, n_pad, nmm;
     double delta, atol;
+    int box;                // mA == 0: the projection is a mask, so it is maintained in place (d[ind] = 0 when ind becomes fixed)
     unsigned long long* mirror; unsigned tag;
 };
 
@@ -942,6 +943,7 @@ __global__ __launch_bounds__(CG_T) void cauchy_init_kernel(CauchyArgs a) {
         a.fixrank[i] = act ? 0 : -1;
         cnt[0] += act ? 1.0 : 0.0;
         a.negg[i] = -a.g[i];
+        if (a.box) a.d[i] = act ? 0.0 : -a.g[i];                // d = projection(lincons, -g) for box constraints (:592)
         a.s[i] = 0.0;
         a.du[i] = fmin(__dsub_rn(a.xupp[i], xi), a.delta);     // :602
         a.dl[i] = fmax(__dsub_rn(a.xlow[i], xi), -a.delta);    // :603
@@ -967,12 +969,14 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     double sums[2] = {0.0, 0.0};
+    double gd[1] = {0.0};
     double th = INF;
     int ind = 0x7fffffff;
     for (int i = tid; i < a.n; i += CG_T) {
         const double di = a.d[i], hdi = a.Hd[i], si = a.s[i];
         sums[0] = fma(si, hdi, sums[0]);
         sums[1] = fma(di, hdi, sums[1]);
+        gd[0] = fma(a.g[i], di, gd[0]);
         if (a.fixrank[i] < 0) {                                   // :547
             double t = INF;
             if (di < 0.0) t = __ddiv_rn(__dsub_rn(a.dl[i], si), di);       // :549
@@ -980,8 +984,6 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
             if (t < th) { th = t; ind = i; }                      // strict <: first minimiser in index order (:555)
         }
     }
-    double gd[1] = {0.0};
-    for (int i = tid; i < a.n; i += CG_T) gd[0] = fma(a.g[i], a.d[i], gd[0]);
     block_reduce<CG_T, 2>(sums, scratch, OpSum(), 0.0);
     block_reduce<CG_T, 1>(gd, scratch, OpSum(), 0.0);
     // arg-min with the smallest index among equal thetas
@@ -1019,7 +1021,12 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
         else { step = th; advance = 1; }                          // :628
     }
     if (step != 0.0 || advance)
-        for (int i = tid; i < a.n; i += CG_T) a.s[i] = __dadd_rn(a.s[i], __dmul_rn(step, a.d[i]));
+        for (int i = tid; i < a.n; i += CG_T) {
+            a.s[i] = __dadd_rn(a.s[i], __dmul_rn(step, a.d[i]));
+            // box constraints: projection!(lincons, -g, d) after add_active!(ind) only zeroes d[ind] (:632) — done by the
+            // thread that owns the element, after it has used the old value
+            if (advance && a.box && i == ind) a.d[i] = 0.0;
+        }
     if (tid == 0) {
         st->rtv = phi_p; st->pHp = phi_pp; st->gamma = th; st->alpha = delta_t;
         st->n_hmul += 1;
