@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int
                                                          double* dinv_out, int* info, int info_base, int reset_info,
                                                          const CgState* gate) {
     if (gate != nullptr && gate->done) return;
-    __shared__ double colbuf[2][64];
+    __shared__ __attribute__((aligned(16))) double colbuf[2][64];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double a[16];
@@ -1334,7 +1334,11 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int
                     const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[jj]), j),
                                                         __builtin_amdgcn_readlane(__double2loint(a[jj]), j));
                     // one reciprocal square root instead of sqrt + 64 divisions: the dependent fp64 chain per step is the cost
-                    const double rinv = rsqrt(piv);
+                    // v_rsq_f64 seed + two Newton steps (y <- y(1.5 - 0.5 x y^2)): full fp64 accuracy for the normal, positive
+                    // pivots of an SPD matrix without the library rsqrt's range handling (the pivot chain is the critical path)
+                    double rinv = __builtin_amdgcn_rsq(piv);
+                    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+                    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
                     if (!(piv > 0.0) && lane == 0 && s_bad == 0) s_bad = j + 1;
                     double lij = 0.0;
                     if (lane == j) { lij = piv * rinv; dinv_mine = rinv; }
@@ -1343,13 +1347,16 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int
                     colbuf[buf][lane] = lij;
                 }
                 __syncthreads();
-                const double lij = colbuf[buf][lane];
+                if (16 * wave + 15 > j) {                           // this wave's panel has columns right of j (wave-uniform)
+                    const double lij = colbuf[buf][lane];
+                    const double* cb = &colbuf[buf][16 * wave];     // the 16 l_kj of this panel: contiguous, broadcast reads
+                    // branch-free: rows above the diagonal and columns <= j get a zero coefficient (columns >= m hold zeros)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const int k = 16 * wave + c;
-                    if (k > j && k < m) {
-                        const double lkj = colbuf[buf][k];          // broadcast read
-                        if (lane >= k) a[c] = fma(-lij, lkj, a[c]);
+                    for (int c = 0; c < 16; ++c) {
+                        const int k = 16 * wave + c;
+                        const double lkj = (k > j) ? cb[c] : 0.0;
+                        const double li = (lane >= k) ? lij : 0.0;
+                        a[c] = fma(-li, lkj, a[c]);
                     }
                 }
                 buf ^= 1;
