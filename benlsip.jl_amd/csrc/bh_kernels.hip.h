@@ -1452,7 +1452,9 @@ __global__ __launch_bounds__(64) void chol_downdate_small_kernel(double* __restr
             const double sn = ak * dk;
             const double t = fma(-sn, sn, 1.0);
             if (!(t > 0.0) && bad == 0) bad = k + 1;
-            const double rc = rsqrt(t);          // 1/c
+            double rc = __builtin_amdgcn_rsq(t);  // 1/c: hardware seed + two Newton steps (t is a normal number in (0, 1])
+            rc = rc * fma(-0.5 * t * rc, rc, 1.5);
+            rc = rc * fma(-0.5 * t * rc, rc, 1.5);
             const double c = t * rc;
             if (lane == k) { row[k] = row[k] * c; dinv = dinv * rc; }
             else if (lane > k) {
