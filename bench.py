@@ -124,6 +124,8 @@ def main():
                     help="wc: well-conditioned J (a handful of CG iterations); ic: columns scaled 10^(-3j/n) (hundreds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-ic-extra", action="store_true",
+                    help="skip the ill-conditioned extra run (its over-launched no-op kernels would pull down rocprofv3's per-kernel average)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,7 +212,7 @@ def main():
             "fused_ms": ms_f, "fused_gbs": st["bytes_per_hmul"] / ms_f / 1e6,
             "note": "back-to-back launches timed with hipEvents on the launch stream (bh_time_kernel), this rank's shard",
         }
-    if world == 1 and not args.no_extras and args.variant == "wc":
+    if world == 1 and not args.no_extras and not args.no_ic_extra and args.variant == "wc":
         # steady-state CG iteration cost on the ill-conditioned variant (23 iterations per subproblem): outside the timed region
         H.close()
         H2, cons2, dv2, _ = setup_instance(bh, rank, world, 1)

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-ic-extra > $OUT/trace.log 2>&1
 grep '^{' $OUT/trace.log > $OUT/bench_line_under_trace.json || true
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $OUT/write.log 2>&1
