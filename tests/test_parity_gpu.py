@@ -840,3 +840,30 @@ def test_row_sharded_products_emulated_on_one_gpu(bh):
     w, st, info = bh.projected_cg(g, H_full, w_l, w_u, cons, 0.01, full_output=True)
     assert int(st) == int(s_sh) and info["iters"] == it_sh
     assert relnorm(w, w_sh) <= 1e-9
+
+
+def test_full_solve_medium_nls_through_c_abi(bh, capsys):
+    """The restated outer iteration (tralcnllss -> solve_subproblem -> inner_step) on a 48-parameter constrained NLS with
+    every hot-path / next-row call on the device (hundreds of minor iterates, Cauchy searches, active-set changes, mu and
+    Hessian updates) against the all-CPU oracle run."""
+    import time
+    from nls_problem import NLSProblem
+    P = NLSProblem(256, 48, 2, seed=1)
+    kw = dict(max_outer_iter=30, max_inner_iter=60)
+    t0 = time.perf_counter()
+    log_ref = []
+    x_ref, y_ref = R.tralcnllss(P.x0, P.r, P.jac_r, P.c, P.jac_c, P.A, P.b, P.x_l, P.x_u, log=log_ref, **kw)
+    t_cpu = time.perf_counter() - t0
+    ops = HipOpsDeviceAll(bh)
+    log = []
+    t0 = time.perf_counter()
+    x, y = R.tralcnllss(P.x0, P.r, P.jac_r, P.c, P.jac_c, P.A, P.b, P.x_l, P.x_u, ops=ops, log=log, **kw)
+    t_gpu = time.perf_counter() - t0
+    obj = lambda z: 0.5 * float(P.r(z) @ P.r(z))
+    with capsys.disabled():
+        print("[full solve n=48 d=256] oracle %.2f s (%d minor iterates), device ops %.2f s (%d); |x - x_ref| = %.2e, obj %.9f vs %.9f"
+              % (t_cpu, len(log_ref), t_gpu, len(log), np.linalg.norm(x - x_ref), obj(x), obj(x_ref)))
+    assert np.linalg.norm(P.c(x)) < 1e-6 and np.linalg.norm(P.A @ x - P.b) < 1e-10
+    assert np.all(x >= P.x_l - 1e-12) and np.all(x <= P.x_u + 1e-12)
+    assert obj(x) == pytest.approx(obj(x_ref), rel=1e-5)
+    assert np.linalg.norm(x - x_ref) <= 1e-4 * np.linalg.norm(x_ref)
