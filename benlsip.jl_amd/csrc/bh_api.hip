@@ -1599,6 +1599,7 @@ int32_t bh_stats_reset(bh_hess* H) {
     const double b = H->stats.bytes_per_hmul;
     H->stats = bh_stats_t{};
     H->stats.bytes_per_hmul = b;
+    H->hmul_seq = 0;          // the first H*p after a reset is always sampled (BH_FLAG_PROFILE)
     return BH_OK;
 }
 
