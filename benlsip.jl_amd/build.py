@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "bh_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "bh_kernels.hip.h"), os.path.join(ROOT, "include", "benlsip_hip.h")]
+DEPS = [SRC, os.path.join(ROOT, "include", "benlsip_hip.h")] + [os.path.join(HERE, "csrc", f) for f in sorted(os.listdir(os.path.join(HERE, "csrc"))) if f.endswith(".h")]
 OUT = os.path.join(HERE, "lib", "libbenlsip_hip.so")
 
 

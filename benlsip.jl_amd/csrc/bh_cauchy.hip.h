@@ -1,0 +1,159 @@
+// bh_cauchy.hip.h — device-resident cauchy_step (breakpoint search, active-set growth)
+// Part of the single translation unit of bh_api.hip (see bh_kernels.hip.h for the layout and design notes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bh_reduce.hip.h"
+#include "bh_cg.hip.h"
+
+namespace bh {
+
+// ------------------------------------------------------------------------------------------
+// cauchy_step on the device — src/basic_tralcnlss.jl:574-639 with next_breakpoint (:536-562) and the initial
+// active_bounds! (src/polyhedral_constraints.jl:203-215).  SURVEY.md §8 "next" row f-3.
+// The loop state reuses CgState (so the row-stream / projection kernels can gate on ->done / ->need_proj):
+//   rtv = phi_p, pHp = phi_pp, gamma = theta, alpha = delta_t, iter = nb_fix, max_iter = n - mA (nmm),
+//   status = index fixed at the last breakpoint (-1: none), approx_solved = min_found, neg_curvature = 1 when no
+//   breakpoint exists (the reference would index fixvars[-1]), pad = breakpoints taken, n_hmul = H*d products.
+// ------------------------------------------------------------------------------------------
+struct CauchyArgs {
+    CgState* st;
+    const double* x; const double* g; const double* xlow; const double* xupp;
+    double* negg; double* d; const double* Hd; double* s; double* dl; double* du;
+    int* fixrank;
+    int n, n_pad, nmm;
+    double delta, atol;
+    int box;                // mA == 0: the projection is a mask, so it is maintained in place (d[ind] = 0 when ind becomes fixed)
+    unsigned long long* mirror; unsigned tag;
+};
+
+__device__ __forceinline__ void publish_cauchy(const CauchyArgs& a, const CgState* st) {
+    if (a.mirror == nullptr) return;
+    const unsigned long long wv = ((unsigned long long)(a.tag & 0xffffu) << 48) | ((unsigned long long)(st->neg_curvature & 0xf) << 44) |
+                                  ((unsigned long long)(st->done & 0xf) << 40) | ((unsigned long long)(st->pad & 0xfffff) << 20) |
+                                  (unsigned long long)(st->n_hmul & 0xfffff);
+    __hip_atomic_store(a.mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// :587-603: s_c = 0; active_bounds!(lincons, x); -g; d_u = min(xupp - x, delta); d_l = max(xlow - x, -delta).
+__global__ __launch_bounds__(CG_T) void cauchy_init_kernel(CauchyArgs a) {
+    __shared__ double scratch[CG_T / 64];
+    double cnt[1] = {0.0};
+    for (int i = a.n + threadIdx.x; i < a.n_pad; i += CG_T) { a.negg[i] = 0.0; a.d[i] = 0.0; a.s[i] = 0.0; a.fixrank[i] = -1; }
+    for (int i = threadIdx.x; i < a.n; i += CG_T) {
+        const double xi = a.x[i];
+        const bool act = (__dsub_rn(xi, a.xlow[i]) <= a.atol) || (__dsub_rn(a.xupp[i], xi) <= a.atol);   // poly:211
+        a.fixrank[i] = act ? 0 : -1;
+        cnt[0] += act ? 1.0 : 0.0;
+        a.negg[i] = -a.g[i];
+        if (a.box) a.d[i] = act ? 0.0 : -a.g[i];                // d = projection(lincons, -g) for box constraints (:592)
+        a.s[i] = 0.0;
+        a.du[i] = fmin(__dsub_rn(a.xupp[i], xi), a.delta);     // :602
+        a.dl[i] = fmax(__dsub_rn(a.xlow[i], xi), -a.delta);    // :603
+    }
+    block_reduce<CG_T, 1>(cnt, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) {
+        CgState* st = a.st;
+        st->rtv = 0.0; st->pHp = 0.0; st->gamma = 0.0; st->alpha = 0.0; st->beta = 0.0; st->tol_cg = 0.0;
+        st->iter = (int)cnt[0]; st->max_iter = a.nmm;
+        st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
+        st->done = 0; st->status = -1; st->n_hmul = 0; st->need_proj = 1; st->pad = 0;
+    }
+}
+
+// One pass: phi_p, phi_pp for the current (d, Hd) (:610-611 / :634-635), the while test (:615), next_breakpoint (:617),
+// the three-way branch (:620-636) including s_c update and the active-set growth of add_active! (poly:240-249).
+__global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
+    constexpr int NW = CG_T / 64;
+    __shared__ double scratch[2 * NW];
+    __shared__ int iscratch[NW];
+    CgState* st = a.st;
+    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    double sums[2] = {0.0, 0.0};
+    double gd[1] = {0.0};
+    double th = INF;
+    int ind = 0x7fffffff;
+    for (int i = tid; i < a.n; i += CG_T) {
+        const double di = a.d[i], hdi = a.Hd[i], si = a.s[i];
+        sums[0] = fma(si, hdi, sums[0]);
+        sums[1] = fma(di, hdi, sums[1]);
+        gd[0] = fma(a.g[i], di, gd[0]);
+        if (a.fixrank[i] < 0) {                                   // :547
+            double t = INF;
+            if (di < 0.0) t = __ddiv_rn(__dsub_rn(a.dl[i], si), di);       // :549
+            else if (di > 0.0) t = __ddiv_rn(__dsub_rn(a.du[i], si), di);  // :551
+            if (t < th) { th = t; ind = i; }                      // strict <: first minimiser in index order (:555)
+        }
+    }
+    block_reduce<CG_T, 2>(sums, scratch, OpSum(), 0.0);
+    block_reduce<CG_T, 1>(gd, scratch, OpSum(), 0.0);
+    // arg-min with the smallest index among equal thetas
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double t2 = __shfl_xor(th, off);
+        const int i2 = __shfl_xor(ind, off);
+        if (t2 < th || (t2 == th && i2 < ind)) { th = t2; ind = i2; }
+    }
+    __syncthreads();
+    if (lane == 0) { scratch[wave] = th; iscratch[wave] = ind; }
+    __syncthreads();
+    th = scratch[0]; ind = iscratch[0];
+    for (int w = 1; w < NW; ++w) {
+        const double t2 = scratch[w];
+        const int i2 = iscratch[w];
+        if (t2 < th || (t2 == th && i2 < ind)) { th = t2; ind = i2; }
+    }
+    if (ind == 0x7fffffff) ind = -1;                              // :544
+
+    const double phi_p = __dadd_rn(sums[0], gd[0]);               // :610 / :634
+    const double phi_pp = sums[1];                                // :611 / :635
+    const int nfix = st->iter;
+    int done = 0, min_found = 0, err = 0, advance = 0;
+    double step = 0.0;
+    const double delta_t = (phi_pp > 0.0) ? __ddiv_rn(-phi_p, phi_pp) : 0.0;     // :618
+    if (!(nfix < a.nmm)) {                                        // :615
+        done = 1;
+    } else if (phi_p >= 0.0) {                                    // :620
+        min_found = 1; done = 1;
+    } else if (phi_p < 0.0 && phi_pp > 0.0 && delta_t < th) {     // :622
+        step = delta_t; min_found = 1; done = 1;                  // :625
+    } else {                                                      // :627
+        if (ind < 0) { err = 1; done = 1; }
+        else { step = th; advance = 1; }                          // :628
+    }
+    if (step != 0.0 || advance)
+        for (int i = tid; i < a.n; i += CG_T) {
+            a.s[i] = __dadd_rn(a.s[i], __dmul_rn(step, a.d[i]));
+            // box constraints: projection!(lincons, -g, d) after add_active!(ind) only zeroes d[ind] (:632) — done by the
+            // thread that owns the element, after it has used the old value
+            if (advance && a.box && i == ind) a.d[i] = 0.0;
+        }
+    if (tid == 0) {
+        st->rtv = phi_p; st->pHp = phi_pp; st->gamma = th; st->alpha = delta_t;
+        st->n_hmul += 1;
+        st->approx_solved = min_found; st->neg_curvature = err;
+        if (advance) {
+            a.fixrank[ind] = 0;                                   // add_active!: fixvars[ind] = true (poly:246)
+            st->iter = nfix + 1; st->status = ind; st->pad += 1;
+        }
+        st->done = done; st->need_proj = done ? 0 : 1;
+        publish_cauchy(a, st);
+    }
+}
+
+// M <- M - a a',  a = column `ind` of A (the variable that just became fixed):  A_free A_free' after add_active!.
+__global__ __launch_bounds__(256) void gram_downdate_kernel(double* __restrict__ M, const double* __restrict__ A, int64_t ldA, int mA,
+                                                            const CgState* st) {
+    if (st->done) return;
+    const int ind = st->status;
+    if (ind < 0) return;
+    const int64_t total = (int64_t)mA * mA;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % mA), k = (int)(e / mA);
+        if (i >= k) M[e] = fma(-A[(int64_t)i * ldA + ind], A[(int64_t)k * ldA + ind], M[e]);
+    }
+}
+
+}  // namespace bh

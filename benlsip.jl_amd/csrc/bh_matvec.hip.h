@@ -1,0 +1,297 @@
+// bh_matvec.hip.h — row-streaming kernels for J v, J'u and the fused single-read J'(W.(J v)); slab reduction; upload transpose; synthetic J
+// Part of the single translation unit of bh_api.hip (see bh_kernels.hip.h for the layout and design notes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bh_reduce.hip.h"
+
+namespace bh {
+
+// ------------------------------------------------------------------------------------------
+// Row-streaming kernel: J·v, J'·u and the fused single-read J'(W ∘ (J v)).
+//   T   threads per workgroup, CPT 16-byte chunks (2 doubles) per thread per row, R rows per step.
+//   A workgroup owns row groups g = blockIdx.x, +gridDim.x, ... (the whole grid marches through
+//   HBM together, like a copy); the next group's loads are issued before the current group's
+//   reduction so they stay in flight across the barrier.
+// ------------------------------------------------------------------------------------------
+enum { MODE_JV = 0, MODE_JTV = 1, MODE_FUSED = 2 };
+
+struct RowStreamArgs {
+    const double* J;        // row-major image, (nrows) x ld
+    int64_t ld;             // doubles per row (multiple of 16)
+    int64_t nrows;          // rows swept by this launch
+    int64_t d_rows;         // rows [0,d_rows) have weight 1, rows >= d_rows weight mu (the C block)
+    int nchunks;            // ld / 2
+    const double* v;        // n_pad doubles (JV, FUSED)
+    const double* u;        // nrows doubles (JTV)
+    double* t_out;          // nrows doubles or NULL (JV)
+    double* partials;       // gridDim.x x ld  (JTV, FUSED)
+    double* sq_partials;    // gridDim.x or NULL (JV: sum_i weight_i * t_i^2, for vthv)
+    double mu;
+    const CgState* state;   // NULL, or skip the launch when state->done
+    int reverse;            // sweep the row groups last-to-first (ping-pong order keeps the tail of J in the Infinity Cache)
+    int accumulate;         // JV: t_out += (column panels of a wide J are swept one launch each)
+    int weighted_u;         // JTV: coefficient u[row] * (row < d_rows ? 1 : mu)  (second pass of the two-pass H*p)
+    int negate;             // JV/FUSED: use -mask(v) instead of v (first CG iteration: p0 = -P(g) for box constraints, :706-708)
+    const int* negmask;     // fixrank (>= 0: fixed -> 0) or NULL, with negate
+};
+
+// NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
+// PF: 1 = issue the next row group's loads before reducing the current one (two register buffers); 0 = one buffer, latency
+// hidden by several co-resident workgroups instead.
+template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1>
+__global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
+    if (a.state != nullptr && a.state->done) return;
+    constexpr int NW = T / 64;
+    __shared__ double red[2][R][NW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t ld2 = a.ld >> 1;   // row stride in double2
+    const double2* __restrict__ J2 = reinterpret_cast<const double2*>(a.J);
+
+    bool act[CPT];
+    double2 vv[CPT], zz[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + k * T;
+        act[k] = c < a.nchunks;
+        vv[k] = make_double2(0.0, 0.0);
+        zz[k] = make_double2(0.0, 0.0);
+        if (MODE != MODE_JTV && act[k]) {
+            vv[k] = reinterpret_cast<const double2*>(a.v)[c];
+            if (a.negate) {
+                int2 f = make_int2(-1, -1);
+                if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
+                vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
+                vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
+            }
+        }
+    }
+
+    const int64_t ngroups = (a.nrows + R - 1) / R;
+    const int64_t G = gridDim.x;
+    double sq_acc = 0.0;
+    int buf = 0;
+
+    double2 A[R][CPT], B[R][CPT];
+
+    auto load_group = [&](double2 (&dst)[R][CPT], int64_t grp) {
+        if (a.reverse) grp = ngroups - 1 - grp;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = grp * R + r;
+            const bool rv = row < a.nrows;
+            const double2* rp = J2 + (rv ? row : 0) * ld2;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                dst[r][k] = make_double2(0.0, 0.0);
+                if (rv && act[k]) {
+                    if (NT) {
+                        const dvec2 t = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rp + tid + k * T));
+                        dst[r][k] = make_double2(t.x, t.y);
+                    } else {
+                        dst[r][k] = rp[tid + k * T];
+                    }
+                }
+            }
+        }
+    };
+
+    auto process = [&](double2 (&X)[R][CPT], int64_t grp) {
+        if (a.reverse) grp = ngroups - 1 - grp;
+        double s[R];
+        if (MODE != MODE_JTV) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    acc = fma(X[r][k].x, vv[k].x, acc);
+                    acc = fma(X[r][k].y, vv[k].y, acc);
+                }
+                s[r] = wave_sum(acc);
+            }
+            if (NW > 1) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) red[buf][r][wave] = s[r];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) t += red[buf][r][w];
+                    s[r] = t;
+                }
+                buf ^= 1;
+            }
+        }
+        if (MODE == MODE_JV && a.t_out != nullptr) {
+            // the R results of the group leave in ONE store instruction (lanes 0..R-1 of wave 0, R*8 contiguous bytes)
+            double mine = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (tid == r) mine = s[r];
+            const int64_t row = grp * R + tid;
+            if (tid < R && row < a.nrows) a.t_out[row] = a.accumulate ? a.t_out[row] + mine : mine;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = grp * R + r;
+            const bool rv = row < a.nrows;
+            if (MODE == MODE_JV) {
+                if (rv) {
+                    const double wgt = (row < a.d_rows) ? 1.0 : a.mu;
+                    sq_acc = fma(wgt * s[r], s[r], sq_acc);
+                }
+            } else {
+                double coef;
+                if (MODE == MODE_JTV) coef = rv ? (a.weighted_u && row >= a.d_rows ? a.mu * a.u[row] : a.u[row]) : 0.0;
+                else coef = (row < a.d_rows) ? s[r] : a.mu * s[r];
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {
+                    zz[k].x = fma(coef, X[r][k].x, zz[k].x);
+                    zz[k].y = fma(coef, X[r][k].y, zz[k].y);
+                }
+            }
+        }
+    };
+
+    int64_t g = blockIdx.x;
+    if (!PF) {
+        for (; g < ngroups; g += G) {
+            load_group(A, g);
+            process(A, g);
+        }
+    } else if (g < ngroups) {
+        load_group(A, g);
+        while (true) {
+            int64_t gn = g + G;
+            if (gn < ngroups) load_group(B, gn);
+            process(A, g);
+            if (gn >= ngroups) break;
+            g = gn;
+            gn = g + G;
+            if (gn < ngroups) load_group(A, gn);
+            process(B, g);
+            if (gn >= ngroups) break;
+            g = gn;
+        }
+    }
+
+    if (MODE == MODE_JV) {
+        if (a.sq_partials != nullptr && tid == 0) a.sq_partials[blockIdx.x] = sq_acc;
+    } else {
+        double2* out = reinterpret_cast<double2*>(a.partials) + (int64_t)blockIdx.x * ld2;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if (act[k]) out[tid + k * T] = zz[k];
+    }
+}
+
+// Sum the G partial rows written by row_stream_kernel into out (fixed order).
+// Block = 256 threads = 16 chunks x 16 row-lanes; grid = ceil(nchunks/16).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __restrict__ partials, int64_t ld,
+                                                              int nchunks, int G, double* __restrict__ out,
+                                                              const CgState* state) {
+    if (state != nullptr && state->done) return;
+    __shared__ double2 sm[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int64_t ld2 = ld >> 1;
+    const double2* P2 = reinterpret_cast<const double2*>(partials);
+    double2 acc = make_double2(0.0, 0.0);
+    if (c < nchunks) {
+        int g = rl;
+        for (; g + 48 < G; g += 64) {
+            const double2 x0 = P2[(int64_t)g * ld2 + c];
+            const double2 x1 = P2[(int64_t)(g + 16) * ld2 + c];
+            const double2 x2 = P2[(int64_t)(g + 32) * ld2 + c];
+            const double2 x3 = P2[(int64_t)(g + 48) * ld2 + c];
+            acc.x += x0.x; acc.y += x0.y;
+            acc.x += x1.x; acc.y += x1.y;
+            acc.x += x2.x; acc.y += x2.y;
+            acc.x += x3.x; acc.y += x3.y;
+        }
+        for (; g < G; g += 16) {
+            const double2 x0 = P2[(int64_t)g * ld2 + c];
+            acc.x += x0.x; acc.y += x0.y;
+        }
+    }
+    sm[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < nchunks) {
+        double2 t = sm[0][cl];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { t.x += sm[r][cl].x; t.y += sm[r][cl].y; }
+        reinterpret_cast<double2*>(out)[c] = t;
+    }
+}
+
+// Sum m doubles (single workgroup) into out[0]; used for the vthv scalar.
+__global__ __launch_bounds__(256) void reduce_scalar_kernel(const double* __restrict__ x, int m, double* out) {
+    __shared__ double scratch[4];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < m; i += 256) acc[0] += x[i];
+    block_reduce<256, 1>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+// sum_i w_i t_i^2 with w_i = 1 (i < d_rows) or mu: vthv for a J swept in column panels.  Single workgroup.
+__global__ __launch_bounds__(1024) void weighted_sqsum_kernel(const double* __restrict__ t, int64_t nrows, int64_t d_rows, double mu,
+                                                               double* __restrict__ out) {
+    __shared__ double scratch[1024 / 64];
+    double acc[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < nrows; i += 1024) {
+        const double ti = t[i];
+        acc[0] = fma((i < d_rows) ? ti : mu * ti, ti, acc[0]);
+    }
+    block_reduce<1024, 1>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+// Column-major (host layout, leading dimension lds) -> row-major padded image.  32x32 tiles via LDS.
+__global__ __launch_bounds__(256) void transpose_cm_to_rm_kernel(const double* __restrict__ src, int64_t lds_, int64_t rows,
+                                                                 int64_t cols, double* __restrict__ dst, int64_t ldd) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t c = c0 + ty + 8 * k, r = r0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[r + c * lds_] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < ldd) dst[r * ldd + c] = (c < cols) ? tile[tx][ty + 8 * k] : 0.0;
+    }
+}
+
+// Synthetic Jacobian of SURVEY.md §8(d), generated in place (row-major, padded columns = 0).
+__device__ __forceinline__ double splitmix_uniform(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return __dsub_rn(__dmul_rn((double)(z >> 11), 2.0 / 9007199254740992.0), 1.0);
+}
+
+__global__ __launch_bounds__(256) void synth_fill_kernel(double* __restrict__ dst, int64_t ldd, int64_t rows, int64_t n,
+                                                         int64_t row0, int64_t d_total, uint64_t seed,
+                                                         const double* __restrict__ colscale, double divisor) {
+    const int64_t total = rows * ldd;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx / ldd, j = idx - i * ldd;
+        double val = 0.0;
+        if (j < n) {
+            val = __ddiv_rn(splitmix_uniform(seed, (uint64_t)(row0 + i) + (uint64_t)j * (uint64_t)d_total), divisor);
+            if (colscale != nullptr) val = __dmul_rn(val, colscale[j]);
+        }
+        dst[idx] = val;
+    }
+}
+
+}  // namespace bh

@@ -1,0 +1,577 @@
+// bh_proj.hip.h — null-space projection: left_mul / left_mul_tr, Gram (VALU and fp64 MFMA), Cholesky (small, blocked, downdate), triangular solves
+// Part of the single translation unit of bh_api.hip (see bh_kernels.hip.h for the layout and design notes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bh_reduce.hip.h"
+#include "bh_cg.hip.h"
+
+namespace bh {
+
+// ------------------------------------------------------------------------------------------
+// Projection kernels (src/polyhedral_constraints.jl:72-136).
+// ------------------------------------------------------------------------------------------
+struct ProjArgs {
+    const double* A;        // row-major mA x ldA image of lineq (NULL when mA == 0)
+    int64_t ldA;
+    int mA, n, nfix, mpp;   // mpp = order of the factor in use (mA + nfix augmented, mA reduced)
+    const int* fixrank;     // n   (-1 free)
+    const int* fixidx;      // nfix
+    const double* L;        // mpp x mpp column-major, lower triangle valid
+    double* tw;             // mpp workspace
+    const CgState* state;   // NULL, or skip unless (!done && need_proj)
+    int reduced;            // 1: reduced form  v_free = r_free - A_free'(A_free A_free')^{-1} A_free r_free, v_fix = 0
+};
+
+__device__ __forceinline__ bool proj_skip(const CgState* st) { return st != nullptr && (st->done || !st->need_proj); }
+
+// Box-only projection: v = fixed ? 0 : r.
+__global__ __launch_bounds__(256) void proj_mask_kernel(const double* __restrict__ r, double* __restrict__ v, const int* fixrank, int n,
+                                                        const CgState* st) {
+    if (proj_skip(st)) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+        v[i] = (fixrank != nullptr && fixrank[i] >= 0) ? 0.0 : r[i];
+}
+
+// left_mul: tw[0:mA] = A x (one workgroup per row: 4 waves share the row, fixed-order combine), and in the augmented
+// form tw[mA+k] = x[fixidx[k]] (:86-98).  Reduced form: the fixed components of x are masked out (A_free x_free).
+// grid = mA + ceil(nfix/256) blocks of 256 (gather blocks only in the augmented form).
+__global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const double* __restrict__ x) {
+    if (proj_skip(a.state)) return;
+    __shared__ double scratch[4];
+    if ((int)blockIdx.x < a.mA) {
+        const int row = blockIdx.x;
+        const double2* rp = reinterpret_cast<const double2*>(a.A + (int64_t)row * a.ldA);
+        const double2* x2 = reinterpret_cast<const double2*>(x);
+        const int2* f2 = reinterpret_cast<const int2*>(a.fixrank);
+        const int nch = (int)(a.ldA >> 1);
+        const bool mask = a.reduced && a.fixrank != nullptr;
+        double acc[1] = {0.0};
+        for (int c = threadIdx.x; c < nch; c += 256) {
+            const double2 av = rp[c];
+            double2 xv = x2[c];
+            if (mask) {
+                const int2 f = f2[c];
+                if (f.x >= 0) xv.x = 0.0;
+                if (f.y >= 0) xv.y = 0.0;
+            }
+            acc[0] = fma(av.x, xv.x, acc[0]);
+            acc[0] = fma(av.y, xv.y, acc[0]);
+        }
+        block_reduce<256, 1>(acc, scratch, OpSum(), 0.0);
+        if (threadIdx.x == 0) a.tw[row] = acc[0];
+    } else if (!a.reduced) {
+        const int k = ((int)blockIdx.x - a.mA) * 256 + threadIdx.x;
+        if (k < a.nfix) a.tw[a.mA + k] = x[a.fixidx[k]];
+    }
+}
+
+// out = r - left_mul_tr(tw)   (:72-84, :116, :134);  with SUBTRACT=false: out = left_mul_tr(tw).
+// Block = 64 chunks x 4 row groups (rows i = rg, rg+4, ...), combined through LDS in fixed order; grid = ceil(nch/64).
+template <bool SUBTRACT>
+__global__ __launch_bounds__(256) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
+    if (proj_skip(a.state)) return;
+    __shared__ double2 sm[4][64];
+    const int nch = (a.n + 1) >> 1;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double2 acc = make_double2(0.0, 0.0);
+    if (c < nch) {
+        const double2* A2 = reinterpret_cast<const double2*>(a.A);
+        const int64_t ld2 = a.ldA >> 1;
+        for (int i = rg; i < a.mA; i += 4) {
+            const double wi = a.tw[i];
+            const double2 av = A2[(int64_t)i * ld2 + c];
+            acc.x = fma(wi, av.x, acc.x);
+            acc.y = fma(wi, av.y, acc.y);
+        }
+    }
+    sm[rg][cl] = acc;
+    __syncthreads();
+    if (rg != 0 || c >= nch) return;
+    acc.x = (sm[0][cl].x + sm[1][cl].x) + (sm[2][cl].x + sm[3][cl].x);
+    acc.y = (sm[0][cl].y + sm[1][cl].y) + (sm[2][cl].y + sm[3][cl].y);
+    const int j0 = 2 * c, j1 = 2 * c + 1;
+    int k0 = -1, k1 = -1;
+    if (a.fixrank != nullptr) { k0 = a.fixrank[j0]; if (j1 < a.n) k1 = a.fixrank[j1]; }
+    if (a.reduced) {
+        // fixed components of the projection are exactly zero
+        if (SUBTRACT) {
+            out[j0] = (k0 >= 0) ? 0.0 : r[j0] - acc.x;
+            if (j1 < a.n) out[j1] = (k1 >= 0) ? 0.0 : r[j1] - acc.y;
+        } else {
+            out[j0] = (k0 >= 0) ? 0.0 : acc.x;
+            if (j1 < a.n) out[j1] = (k1 >= 0) ? 0.0 : acc.y;
+        }
+        return;
+    }
+    if (k0 >= 0) acc.x += a.tw[a.mA + k0];
+    if (k1 >= 0) acc.y += a.tw[a.mA + k1];
+    if (SUBTRACT) {
+        out[j0] = r[j0] - acc.x;
+        if (j1 < a.n) out[j1] = r[j1] - acc.y;
+    } else {
+        out[j0] = acc.x;
+        if (j1 < a.n) out[j1] = acc.y;
+    }
+}
+
+// Reduced-form factor, built on the device whenever the active set changes (bh_proj_set_active):
+//   M = A_free A_free'  (lower triangle, column-major mA x mA): one wave per entry (i >= k).
+__global__ __launch_bounds__(256) void gram_free_kernel(const double* __restrict__ A, int64_t ldA, int mA, const int* __restrict__ fixrank,
+                                                        double* __restrict__ M) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // packed lower-triangular index
+    const int64_t total = (int64_t)mA * (mA + 1) / 2;
+    if (e >= total) return;
+    // e = i*(i+1)/2 + k, 0 <= k <= i
+    int i = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((int64_t)(i + 1) * (i + 2) / 2 <= e) ++i;
+    while ((int64_t)i * (i + 1) / 2 > e) --i;
+    const int k = (int)(e - (int64_t)i * (i + 1) / 2);
+    const double2* ri = reinterpret_cast<const double2*>(A + (int64_t)i * ldA);
+    const double2* rk = reinterpret_cast<const double2*>(A + (int64_t)k * ldA);
+    const int2* f2 = reinterpret_cast<const int2*>(fixrank);
+    const int nch = (int)(ldA >> 1);
+    double acc = 0.0;
+    for (int c = lane; c < nch; c += 64) {
+        const double2 x = ri[c], y = rk[c];
+        int2 f = make_int2(-1, -1);
+        if (fixrank != nullptr) f = f2[c];
+        if (f.x < 0) acc = fma(x.x, y.x, acc);
+        if (f.y < 0) acc = fma(x.y, y.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) M[i + (int64_t)k * mA] = acc;
+}
+
+// M = A_free A_free' on the matrix cores: the one genuinely GEMM-shaped product around the hot path (mA x n x mA, fp64).
+// One workgroup (16 waves) per 16 x 16 lower tile; v_mfma_f64_16x16x4_f64 with A_op[i][k] = Af[16 ti + i][c + k],
+// B_op[k][j] = Af[16 tk + j][c + k]  (lane l holds i or j = l & 15 and k = l >> 4; C/D: col = l & 15, row = (l >> 4) + 4 reg).
+// The k index is permuted so that lane group l >> 4 owns 4 CONSECUTIVE columns per 16-column super-step (one 32-byte load
+// per lane and operand, 128 contiguous bytes per matrix row); the 16 waves split the super-steps and are combined through
+// LDS in fixed order (bit-reproducible).  Fixed variables are masked out of the A operand (A_free = A with those columns 0).
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+constexpr int GRAM_T = 1024;     // 16 waves split the k range of one tile (a tile has only mA-independent work: n/16 super-steps)
+__global__ __launch_bounds__(GRAM_T) void gram_free_mfma_kernel(const double* __restrict__ A, int64_t ldA, int mA,
+                                                                const int* __restrict__ fixrank, double* __restrict__ M) {
+    constexpr int NW = GRAM_T / 64;
+    __shared__ double red[NW][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // packed lower-triangular tile index -> (ti, tk), ti >= tk
+    const int e = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+    while (ti * (ti + 1) / 2 > e) --ti;
+    const int tk = e - ti * (ti + 1) / 2;
+    const int ri = 16 * ti + (lane & 15), rk = 16 * tk + (lane & 15), kq = lane >> 4;
+    const bool vi = ri < mA, vk = rk < mA;
+    const double* pa = A + (int64_t)(vi ? ri : 0) * ldA + 4 * kq;
+    const double* pb = A + (int64_t)(vk ? rk : 0) * ldA + 4 * kq;
+    const int nsuper = (int)(ldA >> 4);          // 16 columns per super-step (ldA is a multiple of 16)
+    dvec4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two independent accumulation chains
+#pragma unroll 4
+    for (int sidx = wave; sidx < nsuper; sidx += NW) {
+        const int64_t c = (int64_t)sidx * 16;
+        double2 a01 = make_double2(0.0, 0.0), a23 = a01, b01 = a01, b23 = a01;
+        if (vi) { a01 = *reinterpret_cast<const double2*>(pa + c); a23 = *reinterpret_cast<const double2*>(pa + c + 2); }
+        if (vk) { b01 = *reinterpret_cast<const double2*>(pb + c); b23 = *reinterpret_cast<const double2*>(pb + c + 2); }
+        if (fixrank != nullptr) {
+            const int4 f = *reinterpret_cast<const int4*>(fixrank + c + 4 * kq);
+            if (f.x >= 0) a01.x = 0.0;
+            if (f.y >= 0) a01.y = 0.0;
+            if (f.z >= 0) a23.x = 0.0;
+            if (f.w >= 0) a23.y = 0.0;
+        }
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, b01.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, b01.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, b23.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, b23.y, acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc0[r] + acc1[r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][lane][r];
+        const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tk + (lane & 15);
+        if (row < mA && col <= row) M[row + (int64_t)col * mA] = t;
+    }
+}
+
+// In-place lower Cholesky of the mA x mA matrix M (column-major, lower triangle), single workgroup, right-looking.
+// info[0] = 0 on success, else 1 + index of the first non-positive pivot (the reference's PosDefException).
+__global__ __launch_bounds__(CG_T) void chol_lower_kernel(const double* __restrict__ Msrc, double* __restrict__ M, int m, int* info,
+                                                          const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    __shared__ double s_piv;
+    const int tid = threadIdx.x;
+    if (tid == 0) info[0] = 0;
+    for (int64_t e = tid; e < (int64_t)m * m; e += CG_T) M[e] = Msrc[e];
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+        if (tid == 0) {
+            const double d = M[j + (int64_t)j * m];
+            if (!(d > 0.0) && info[0] == 0) info[0] = j + 1;
+            s_piv = sqrt(d);
+        }
+        __syncthreads();
+        const double piv = s_piv;
+        for (int i = j + tid; i < m; i += CG_T) M[i + (int64_t)j * m] = (i == j) ? piv : M[i + (int64_t)j * m] / piv;
+        __syncthreads();
+        // trailing update of the lower triangle: M[i][k] -= L[i][j]*L[k][j], j < k <= i.  32 x 32 thread tiles over the
+        // lower triangle (tx along i: coalesced in the column-major matrix; no integer division per element).
+        const int rem = m - j - 1;
+        const int tx = tid & 31, ty = tid >> 5;
+        const double* colj = M + (int64_t)j * m + (j + 1);
+        for (int kb = 0; kb < rem; kb += 32) {
+            const int kk = kb + ty;
+            const double lkj = (kk < rem) ? colj[kk] : 0.0;
+            for (int ib = kb; ib < rem; ib += 32) {
+                const int ii = ib + tx;
+                if (ii < rem && kk < rem && ii >= kk) {
+                    double* e = M + (int64_t)(j + 1 + kk) * m + (j + 1 + ii);
+                    *e = fma(-colj[ii], lkj, *e);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Reduced-form factor for mA <= 64: right-looking Cholesky on 256 threads.  lane = row, wave w owns the 16-column panel
+// [16w, 16w+16) of that row in REGISTERS (statically indexed: the column loop is unrolled per panel); each step the
+// owning wave publishes column j through a double-buffered 64-entry LDS vector (one barrier per step) and every wave
+// applies the rank-one update to its panel.  (History: fully unrolled one-wave register version 100 us, instruction-fetch
+// bound; one-wave LDS loops 66-170 us, latency bound.)  Writes L (lower, column-major m x m) and the reciprocal diagonal
+// dinv[m] right after the matrix (dst + m*m), which turns the substitutions' divisions into multiplications.
+//   Strided form: src/dst are the top-left corners of an nb x nb (nb <= 64) block inside matrices with leading dimensions
+//   ld_src / ld_dst (in-place allowed); dinv_out receives the reciprocal diagonal; pivot failures are reported as
+//   info_base + column + 1.  reset_info: write 0 on success (stand-alone use) — blocked/in-loop callers only ever raise it.
+__global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int64_t ld_src, double* M, int64_t ld_dst, int m,
+                                                         double* dinv_out, int* info, int info_base, int reset_info,
+                                                         const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    __shared__ __attribute__((aligned(16))) double colbuf[2][64];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int k = 16 * wave + c;
+        a[c] = (lane < m && k < m && k <= lane) ? Msrc[lane + (int64_t)k * ld_src] : 0.0;
+    }
+    if (tid == 0) s_bad = 0;
+    double dinv_mine = 0.0;
+    int buf = 0;
+    __syncthreads();
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = 16 * p + jj;
+            if (j < m) {                                    // uniform
+                if (wave == p) {
+                    const double piv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[jj]), j),
+                                                        __builtin_amdgcn_readlane(__double2loint(a[jj]), j));
+                    // one reciprocal square root instead of sqrt + 64 divisions: the dependent fp64 chain per step is the cost
+                    // v_rsq_f64 seed + two Newton steps (y <- y(1.5 - 0.5 x y^2)): full fp64 accuracy for the normal, positive
+                    // pivots of an SPD matrix without the library rsqrt's range handling (the pivot chain is the critical path)
+                    double rinv = __builtin_amdgcn_rsq(piv);
+                    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+                    rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+                    if (!(piv > 0.0) && lane == 0 && s_bad == 0) s_bad = j + 1;
+                    double lij = 0.0;
+                    if (lane == j) { lij = piv * rinv; dinv_mine = rinv; }
+                    else if (lane > j) lij = a[jj] * rinv;
+                    a[jj] = lij;
+                    colbuf[buf][lane] = lij;
+                }
+                __syncthreads();
+                if (16 * wave + 15 > j) {                           // this wave's panel has columns right of j (wave-uniform)
+                    const double lij = colbuf[buf][lane];
+                    const double* cb = &colbuf[buf][16 * wave];     // the 16 l_kj of this panel: contiguous, broadcast reads
+                    // branch-free: rows above the diagonal and columns <= j get a zero coefficient (columns >= m hold zeros)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        const int k = 16 * wave + c;
+                        const double lkj = (k > j) ? cb[c] : 0.0;
+                        const double li = (lane >= k) ? lij : 0.0;
+                        a[c] = fma(-li, lkj, a[c]);
+                    }
+                }
+                buf ^= 1;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int k = 16 * wave + c;
+        if (lane < m && k < m && k <= lane) M[lane + (int64_t)k * ld_dst] = a[c];
+    }
+    if (dinv_out != nullptr && lane < m && wave == (lane >> 4)) dinv_out[lane] = dinv_mine;
+    __syncthreads();
+    if (tid == 0) {
+        if (s_bad != 0) info[0] = info_base + s_bad;
+        else if (reset_info) info[0] = 0;
+    }
+}
+
+// ---- blocked Cholesky for m > 64: potrf (chol_small_kernel on the 64 x 64 diagonal block) / trsm / syrk per panel ------
+// Copy the lower triangle (gate-aware) so that the factorisation can run in place on dst.
+__global__ __launch_bounds__(256) void copy_lower_kernel(const double* __restrict__ src, double* __restrict__ dst, int m, int* info,
+                                                         const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    const int64_t total = (int64_t)m * m;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % m), k = (int)(e / m);
+        if (i >= k) dst[e] = src[e];
+    }
+    if (gate == nullptr && blockIdx.x == 0 && threadIdx.x == 0) info[0] = 0;
+}
+
+// L21 <- A21 L11^{-T}: rows [r0, m) of the panel [k0, k0+nb).  One thread per row; L11 (lower, nb x nb) and its reciprocal
+// diagonal in LDS; column j of the row is finished before column j+1 (own earlier columns are re-read from global memory).
+__global__ __launch_bounds__(256) void chol_trsm_kernel(double* __restrict__ M, int m, int k0, int nb, const double* __restrict__ dinv,
+                                                        const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    __shared__ double l11[64 * 65];
+    __shared__ double di[64];
+    for (int e = threadIdx.x; e < nb * nb; e += 256) {
+        const int i = e % nb, k = e / nb;
+        l11[i * 65 + k] = (i >= k) ? M[(k0 + i) + (int64_t)(k0 + k) * m] : 0.0;
+    }
+    if ((int)threadIdx.x < nb) di[threadIdx.x] = dinv[threadIdx.x];
+    __syncthreads();
+    const int r = k0 + nb + blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    for (int j = 0; j < nb; ++j) {
+        double acc = M[r + (int64_t)(k0 + j) * m];
+#pragma unroll 8
+        for (int c = 0; c < j; ++c) acc = fma(-M[r + (int64_t)(k0 + c) * m], l11[j * 65 + c], acc);
+        M[r + (int64_t)(k0 + j) * m] = acc * di[j];
+    }
+}
+
+// A22 <- A22 - L21 L21' (lower triangle only): 16 x 16 thread tiles, each thread one element, nb-long dot product of two
+// rows of the panel (column-major: consecutive threads along i read consecutive addresses).
+__global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ M, int m, int k0, int nb, const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    const int base = k0 + nb;
+    const int i = base + blockIdx.x * 16 + (threadIdx.x & 15);
+    const int k = base + blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (blockIdx.y > blockIdx.x || i >= m || k >= m || i < k) return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < nb; ++c) acc = fma(M[i + (int64_t)(k0 + c) * m], M[k + (int64_t)(k0 + c) * m], acc);
+    M[i + (int64_t)k * m] -= acc;
+}
+
+// Rank-one Cholesky DOWNDATE: L L' <- L L' - a a' with a = column `ind` (state->status) of A — what add_active! does to
+// A_free A_free' when one more variable becomes fixed.  O(m^2) instead of refactoring (O(m^3)); hyperbolic rotations in
+// the reciprocal-diagonal form: s = a_k / l_kk, c = sqrt(1 - s^2), l_kk <- c l_kk, l_ik <- (l_ik - s a_i)/c,
+// a_i <- c a_i - s l_ik.  m <= 64: one wave, row i of L in lane i's registers, 64 unrolled steps of two v_readlane
+// broadcasts + one rsqrt.  A non-positive 1 - s^2 (the downdated matrix is no longer positive definite) raises info.
+__global__ __launch_bounds__(64) void chol_downdate_small_kernel(double* __restrict__ L, const double* __restrict__ A, int64_t ldA, int m,
+                                                                 int* info, const CgState* st) {
+    if (st->done) return;
+    const int ind = st->status;
+    if (ind < 0) return;
+    const int lane = threadIdx.x;
+    double row[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) row[k] = (lane < m && k <= lane && k < m) ? L[lane + (int64_t)k * m] : 0.0;
+    double dinv = (lane < m) ? L[(int64_t)m * m + lane] : 0.0;
+    double a = (lane < m) ? A[(int64_t)lane * ldA + ind] : 0.0;
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        if (k < m) {
+            const double ak = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), k), __builtin_amdgcn_readlane(__double2loint(a), k));
+            const double dk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dinv), k),
+                                               __builtin_amdgcn_readlane(__double2loint(dinv), k));
+            const double sn = ak * dk;
+            const double t = fma(-sn, sn, 1.0);
+            if (!(t > 0.0) && bad == 0) bad = k + 1;
+            double rc = __builtin_amdgcn_rsq(t);  // 1/c: hardware seed + two Newton steps (t is a normal number in (0, 1])
+            rc = rc * fma(-0.5 * t * rc, rc, 1.5);
+            rc = rc * fma(-0.5 * t * rc, rc, 1.5);
+            const double c = t * rc;
+            if (lane == k) { row[k] = row[k] * c; dinv = dinv * rc; }
+            else if (lane > k) {
+                const double lik = (row[k] - sn * a) * rc;
+                a = fma(c, a, -sn * lik);
+                row[k] = lik;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 64; ++k)
+        if (lane < m && k <= lane && k < m) L[lane + (int64_t)k * m] = row[k];
+    if (lane < m) L[(int64_t)m * m + lane] = dinv;
+    if (lane == 0 && bad != 0) info[0] = bad;
+}
+
+// The same for any m: one workgroup, L in global memory (column k is contiguous), a in LDS.
+__global__ __launch_bounds__(CG_T) void chol_downdate_kernel(double* __restrict__ L, const double* __restrict__ A, int64_t ldA, int m,
+                                                             int* info, const CgState* st) {
+    if (st->done) return;
+    const int ind = st->status;
+    if (ind < 0) return;
+    extern __shared__ __attribute__((aligned(16))) double a_sh[];      // m doubles
+    __shared__ double s_c, s_s, s_rc;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < m; i += CG_T) a_sh[i] = A[(int64_t)i * ldA + ind];
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        double* colk = L + (int64_t)k * m;
+        if (tid == 0) {
+            const double lkk = colk[k];
+            const double sn = a_sh[k] / lkk;
+            const double t = fma(-sn, sn, 1.0);
+            if (!(t > 0.0) && info[0] == 0) info[0] = k + 1;
+            const double c = sqrt(t);
+            colk[k] = c * lkk;
+            s_c = c; s_s = sn; s_rc = 1.0 / c;
+        }
+        __syncthreads();
+        const double c = s_c, sn = s_s, rc = s_rc;
+        for (int i = k + 1 + tid; i < m; i += CG_T) {
+            const double lik = (colk[i] - sn * a_sh[i]) * rc;
+            a_sh[i] = fma(c, a_sh[i], -sn * lik);
+            colk[i] = lik;
+        }
+        __syncthreads();
+    }
+}
+
+// tw <- L' \ (L \ tw) for m <= 64 (reduced form).  256 threads stage L into an LDS tile (all loads in flight at once,
+// row stride 65: conflict-free both row- and column-wise); wave 0 then runs the 2 x m dependent steps
+// (readlane + LDS read + fma) with the reciprocal diagonal from chol_small_kernel.
+__global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
+    if (proj_skip(a.state)) return;
+    __shared__ double t[64 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = a.mpp;
+    const double* __restrict__ L = a.L;
+    double tmp[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int k = 16 * wave + c;
+        tmp[c] = (lane < m && k < m && k <= lane) ? L[lane + (int64_t)k * m] : 0.0;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) t[lane * 65 + 16 * wave + c] = tmp[c];
+    __syncthreads();
+    if (wave != 0) return;
+    const double di = (lane < m) ? L[(int64_t)m * m + lane] : 0.0;
+    double xi = (lane < m) ? a.tw[lane] : 0.0;
+#pragma unroll 8
+    for (int j = 0; j < m; ++j) {                           // forward: L y = t
+        const double lij = t[lane * 65 + j];
+        if (lane == j) xi = xi * di;
+        const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
+                                           __builtin_amdgcn_readlane(__double2loint(xi), j));
+        if (lane > j) xi = fma(-lij, xj, xi);
+    }
+#pragma unroll 8
+    for (int j = m - 1; j >= 0; --j) {                      // backward: L' w = y   (L[j][i] = t[j*65 + i], consecutive lanes)
+        const double lji = t[j * 65 + lane];
+        if (lane == j) xi = xi * di;
+        const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), j),
+                                           __builtin_amdgcn_readlane(__double2loint(xi), j));
+        if (lane < j) xi = fma(-lji, xj, xi);
+    }
+    if (lane < m) a.tw[lane] = xi;
+}
+
+// tw <- L' \ (L \ tw)   (:114-115, :132-133).  Single workgroup, 64-wide blocked substitution;
+// the diagonal block is staged through LDS (coalesced column reads, conflict-free padded tile) and
+// solved by one wave with v_readlane broadcasts; trailing updates use all 16 waves.
+// Dynamic LDS: mpp doubles (the vector) + 64*65 doubles (tile).
+__global__ __launch_bounds__(CG_T) void trsv_pair_kernel(ProjArgs a) {
+    if (proj_skip(a.state)) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int m = a.mpp;
+    double* x = smem;
+    double* tile = smem + ((m + 1) & ~1);    // [64][65]
+    const double* __restrict__ L = a.L;
+    const int64_t ld = m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < m; i += CG_T) x[i] = a.tw[i];
+    __syncthreads();
+
+    // ---- forward: L y = t ----
+    for (int j0 = 0; j0 < m; j0 += 64) {
+        const int nb = min(64, m - j0);
+        for (int e = tid; e < 64 * 64; e += CG_T) {
+            const int rr = e & 63, cc = e >> 6;
+            tile[rr * 65 + cc] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane i owns unknown j0+i; column jj of the block is tile[i*65 + jj] (conflict-free: stride 65)
+            double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+#pragma unroll 8
+            for (int jj = 0; jj < nb; ++jj) {
+                const double ljj = tile[jj * 65 + jj];
+                const double lij = tile[lane * 65 + jj];
+                const double xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
+                                                   __builtin_amdgcn_readlane(__double2loint(xi), jj));
+                const double xj = xs / ljj;
+                if (lane == jj) xi = xj;
+                else if (lane > jj) xi = fma(-lij, xj, xi);
+            }
+            if (lane < nb) x[j0 + lane] = xi;
+        }
+        __syncthreads();
+        for (int i = j0 + nb + tid; i < m; i += CG_T) {
+            double acc = 0.0;
+            for (int jj = 0; jj < nb; ++jj) acc = fma(L[i + (int64_t)(j0 + jj) * ld], x[j0 + jj], acc);
+            x[i] -= acc;
+        }
+        __syncthreads();
+    }
+
+    // ---- backward: L' w = y ----
+    const int nblk = (m + 63) / 64;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int j0 = b * 64;
+        const int nb = min(64, m - j0);
+        // x[j0+c] -= sum_{k >= j0+nb} L[k, j0+c] * x[k]   (column segments are contiguous: wave per column)
+        for (int c = wave; c < nb; c += CG_T / 64) {
+            double acc = 0.0;
+            const double* col = L + (int64_t)(j0 + c) * ld;
+            for (int k = j0 + nb + lane; k < m; k += 64) acc = fma(col[k], x[k], acc);
+            acc = wave_sum(acc);
+            if (lane == 0) x[j0 + c] -= acc;
+        }
+        for (int e = tid; e < 64 * 64; e += CG_T) {
+            const int rr = e & 63, cc = e >> 6;
+            tile[rr * 65 + cc] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // lane i owns unknown j0+i and needs L[jj, i] for jj > i: tile[jj*65 + i] (consecutive lanes, conflict-free)
+            double xi = (lane < nb) ? x[j0 + lane] : 0.0;
+#pragma unroll 8
+            for (int jj = nb - 1; jj >= 0; --jj) {
+                const double ljj = tile[jj * 65 + jj];
+                const double lji = tile[jj * 65 + lane];
+                const double xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
+                                                   __builtin_amdgcn_readlane(__double2loint(xi), jj));
+                const double xj = xs / ljj;
+                if (lane == jj) xi = xj;
+                else if (lane < jj) xi = fma(-lji, xj, xi);
+            }
+            if (lane < nb) x[j0 + lane] = xi;
+        }
+        __syncthreads();
+    }
+
+    for (int i = tid; i < m; i += CG_T) a.tw[i] = x[i];
+}
+
+}  // namespace bh

@@ -1,0 +1,101 @@
+// bh_reduce.hip.h — wave64 / workgroup reductions (DPP + permlane swaps) and the device-resident loop state
+// Part of the single translation unit of bh_api.hip (see bh_kernels.hip.h for the layout and design notes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bh {
+
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// wave64 reductions: DPP inside a 16-lane row, v_permlane16_swap / v_permlane32_swap across
+// rows (gfx950).  Butterfly form: every lane ends with the same bits (a+b == b+a).
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+// Julia's min(): NaN-propagating (src/basic_tralcnlss.jl:803,805 use min(gamma, ...)).
+struct OpMinNan {
+    __device__ __forceinline__ double operator()(double a, double b) const {
+        return (a != a) ? a : ((b != b) ? b : (a < b ? a : b));
+    }
+};
+
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double x, Op op) {
+    x = op(x, dpp_mov_f64<0xB1>(x));   // quad_perm [1,0,3,2]   lane ^ 1
+    x = op(x, dpp_mov_f64<0x4E>(x));   // quad_perm [2,3,0,1]   lane ^ 2
+    x = op(x, dpp_mov_f64<0x141>(x));  // row_half_mirror       7 - lane (mod 8)
+    x = op(x, dpp_mov_f64<0x140>(x));  // row_mirror            15 - lane (mod 16)
+    {   // rows 0<->1, 2<->3
+        unsigned lo = __double2loint(x), hi = __double2hiint(x);
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = op(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    {   // halves 0<->1
+        unsigned lo = __double2loint(x), hi = __double2hiint(x);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = op(__hiloint2double(b[0], a[0]), __hiloint2double(b[1], a[1]));
+    }
+    return x;
+}
+__device__ __forceinline__ double wave_sum(double x) { return wave_reduce(x, OpSum()); }
+__device__ __forceinline__ double wave_min(double x) { return wave_reduce(x, OpMinNan()); }
+
+// Block-wide reduction of NV values at once; fixed combination order -> bit-reproducible.
+// `scratch` holds NV * (T/64) doubles.  Every thread returns the same totals.
+template <int T, int NV, class Op>
+__device__ __forceinline__ void block_reduce(double (&x)[NV], double* scratch, Op op, double identity) {
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) x[i] = wave_reduce(x[i], op);
+    if (NW == 1) return;
+    __syncthreads();   // scratch may still be read from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[i * NW + wave] = x[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double t = identity;
+        for (int w = 0; w < NW; ++w) t = op(t, scratch[i * NW + w]);
+        x[i] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Device-resident CG state (one per bh_pcg call).  Mirrors the locals of projected_cg,
+// src/basic_tralcnlss.jl:702-718.
+// ------------------------------------------------------------------------------------------
+struct CgState {
+    double rtv, tol_cg, pHp, alpha, gamma, beta;
+    int iter;        // reference `iter` (starts at 1, :713)
+    int max_iter;    // 2*(n - mA - nfix), :714
+    int approx_solved, outside_region, neg_curvature;   // :716-718
+    int done;        // loop condition :720 is false
+    int status;      // BH_CG_*
+    int n_hmul;      // H*p products performed
+    int need_proj;   // general path: step_a decided to continue -> projection + step_b run
+    int pad;
+};
+
+// Self-test of the wave reduction network (bh_selftest): out[wave] = sum, out[16 + wave] = min.
+__global__ __launch_bounds__(256) void selftest_wave_kernel(const double* in, double* out) {
+    const double x = in[threadIdx.x];
+    const double s = wave_sum(x), mn = wave_min(x);
+    out[threadIdx.x] = s;
+    out[256 + threadIdx.x] = mn;
+}
+
+}  // namespace bh
