@@ -171,6 +171,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = H.stats()
+    replicas_identical = None
+    if dist is not None:
+        # Lock-step check (outside the timed region): w is replicated state, every rank must hold the SAME BITS — the
+        # launch-ahead schedule relies on it.  Compare a checksum of the bit patterns across ranks.
+        bits = dv["w"].download().view(np.int64)
+        chk = int(np.bitwise_xor.reduce(bits)) ^ (int(iters) << 20) ^ int(n_hmul)
+        lo_hi = torch.tensor([chk, -chk], dtype=torch.int64, device="cuda")
+        dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(int(lo_hi[0].item()) == chk and int(lo_hi[1].item()) == -chk)
+        flag = torch.tensor([1 if replicas_identical else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        replicas_identical = bool(flag.item())
 
     traffic, traffic_src = pmc_traffic() if world == 1 else (None, None)
     ms_per_step = 1e3 * elapsed / args.steps
@@ -192,6 +204,7 @@ def main():
             "cg_status": status.name, "cg_iters_per_subproblem": iters - 1, "hmul_per_subproblem": n_hmul,
         },
         "subproblems_per_s_global": args.steps / elapsed,
+        "replicas_bitwise_identical": replicas_identical,
         "cg_iters_per_s": (iters - 1) * args.steps / elapsed,
         "ms_per_cg_iteration": ms_per_step / max(n_hmul, 1),
         "roofline": {

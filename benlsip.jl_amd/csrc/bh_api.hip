@@ -784,10 +784,16 @@ int32_t bh_set_option(const char* key, int64_t value) {
 // ---- multi-GPU -----------------------------------------------------------------------------
 static int32_t load_rccl() {
     if (g_ctx.rccl_lib) return BH_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // BH_RCCL_LIB names a specific build (the multi-process test points it at a host-staged stand-in so that two ranks
+    // can share the one GPU of a test box; RCCL itself refuses duplicate devices).  Otherwise by SONAME: glibc hands
+    // back the copy the process has already mapped (e.g. the one libtorch_hip.so brought in), so there is one RCCL
+    // per process.
+    const char* names[] = {getenv("BH_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {
-        g_ctx.rccl_lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (!nm || !*nm) continue;
+        g_ctx.rccl_lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         if (g_ctx.rccl_lib) break;
+        if (nm == names[0]) return fail(BH_ERR_RCCL, std::string("dlopen(BH_RCCL_LIB=") + nm + "): " + dlerror());
     }
     if (!g_ctx.rccl_lib) return fail(BH_ERR_RCCL, std::string("dlopen(librccl): ") + dlerror());
 #define BH_SYM(field, name)                                                          \
