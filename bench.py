@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 D_PER_GPU = 65536
 N_COLS = 4096
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_CEILING_GBS = 6290.0   # the same guide's measured float4-copy figure (read + write streams; this path is read-only)
 
 
 def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS):
@@ -210,6 +211,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "row_stream_kernel<256,8,4,MODE_FUSED,NT> (single-read J'(Jp), non-temporal loads)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "frac_of_guide_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": st["bytes_per_hmul"], "avg_launch_ms": hmul_ms,
             "launches_timed": st["hmul_timed"],
