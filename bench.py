@@ -229,14 +229,15 @@ def main():
         }
     if world == 1 and not args.no_extras and not args.no_ic_extra and args.variant == "wc":
         # steady-state CG iteration cost on the ill-conditioned variant (23 iterations per subproblem): outside the timed region
-        H.close()
+        # (the first handle stays allocated: freeing 2 GiB here makes the driver scrub it in the background, which took
+        # ~5 % of the HBM bandwidth from the next ~60 ms of kernels — tools/ic_transient.py)
         H2, cons2, dv2, _ = setup_instance(bh, rank, world, 1)
-        run_steps(bh, H2, cons2, dv2, kappa2, 2)
+        run_steps(bh, H2, cons2, dv2, kappa2, 3)
         barrier()
         t1 = time.perf_counter()
-        st2, it2, nh2 = run_steps(bh, H2, cons2, dv2, kappa2, 5)
+        st2, it2, nh2 = run_steps(bh, H2, cons2, dv2, kappa2, 10)
         barrier()
-        el2 = (time.perf_counter() - t1) / 5
+        el2 = (time.perf_counter() - t1) / 10
         line["ic_variant"] = {"workload": "same instance with columns of J scaled by 10^(-3j/n)", "cg_status": st2.name,
                               "hmul_per_subproblem": nh2, "ms_per_subproblem": 1e3 * el2, "ms_per_cg_iteration": 1e3 * el2 / max(nh2, 1),
                               "subproblems_per_s": 1.0 / el2,

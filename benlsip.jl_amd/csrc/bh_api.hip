@@ -48,7 +48,7 @@ struct Ctx {
     // options
     int64_t opt_blocks_per_cu = 0;   // 0 = per-config default
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
-    int64_t opt_batch = 4;           // CG iterations launched ahead of the host's done-flag poll
+    int64_t opt_batch = 0;           // CG iterations launched ahead of the host's done-flag poll; 0 = by problem size (auto_batch)
     int64_t opt_chol_blocked = 1;    // mA > 64: blocked potrf/trsm/syrk chain (0: one-workgroup right-looking kernel)
     int64_t opt_chol_downdate = 1;   // Cauchy search: rank-one downdate of the factor per breakpoint (0: downdate the Gram matrix and refactor)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
@@ -720,7 +720,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     BH_TRY(dev_alloc(&g_ctx.scratch_dev, 1024));
     if (const char* s = getenv("BH_RS_VARIANT")) g_ctx.opt_variant = atoll(s);
     if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = atoll(s);
-    if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(1, atoll(s));
+    if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(0, atoll(s));
     if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_PROJ_FORM")) g_ctx.opt_proj_form = atoll(s) ? 1 : 0;
     g_ctx.init = true;
@@ -769,7 +769,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!key) return fail(BH_ERR_INVALID_ARG, "NULL key");
     if (!strcmp(key, "rs_variant")) { g_ctx.opt_variant = value; return BH_OK; }
     if (!strcmp(key, "blocks_per_cu")) { g_ctx.opt_blocks_per_cu = value; return BH_OK; }
-    if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(1, value); return BH_OK; }
+    if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(0, value); return BH_OK; }
     if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
@@ -1154,6 +1154,20 @@ struct PcgFin { int done, status, iter, n_hmul; };
 
 // Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
 // still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
+// How many iterations the host enqueues per launch-ahead batch.  One batch is always in flight while the host waits for
+// the one before it, so the GPU never idles as long as the host can enqueue a batch faster than the GPU runs one; every
+// iteration enqueued past the exit is a gated no-op that still costs ~1.5 us per kernel (measured, tools/dispatch_floor.py)
+// and, with several ranks, a full all-reduce.  Long iterations (large J) therefore want batch 1, short ones a deeper queue.
+// Measured at config 3 "ic" (23 iterations of 315 us): 7.247 ms per subproblem at batch 1, 7.281 at 4, 7.775 at 64.
+static int launch_batch_size(const bh_hess* H) {
+    if (g_ctx.opt_batch > 0) return (int)g_ctx.opt_batch;
+    const double est_us = H->stats.bytes_per_hmul / 7.0e6;      // ~7 TB/s streaming rate
+    return est_us >= 100.0 ? 1 : est_us >= 40.0 ? 2 : 4;
+}
+// The first batch is sized by the previous call on the handle (consecutive subproblems of a minor loop behave alike):
+// an exact prediction means no gated launches and no host round trip inside the loop at all.
+constexpr int kFirstBatchCap = 32;
+
 static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* wlp, const double* wup, double* wp, bool w_in_ws,
                        double kappa2, double atol_negcurv, double atol_f2b, int64_t trace_cap, PcgFin* fin_out, double* hw = nullptr) {
     const int64_t n = H->n, n_pad = H->ld;
@@ -1216,7 +1230,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // cheap (~3 trivial kernels per iteration) but not free.  First a batch sized by the previous call on this handle
     // (consecutive subproblems of a minor loop behave alike), then, if the loop is still running, launch-ahead batches:
     // batch k+1 is enqueued before the host looks at batch k's state, so the GPU never waits for the host.
-    const int batch = (int)g_ctx.opt_batch;
+    const int batch = launch_batch_size(H);
     int launched = 0;
     auto launch_batch = [&](int nb) -> int32_t {
         nb = std::min(nb, max_iter - launched);
@@ -1231,7 +1245,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // while launch-ahead batches run).  done_by(target) is that rank-independent predicate.
     MirrorWord mw{};
     auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
-    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, 8) : std::min(batch, 2);
+    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : std::min(batch, 2);
     BH_TRY(launch_batch(first));
     BH_TRY(wait_mirror(c, a.tag, launched, &mw));
     if (!done_by(launched) && launched < max_iter) {
@@ -1511,21 +1525,25 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
         return BH_OK;
     };
     MirrorWord mw{};
-    const int batch = (int)g_ctx.opt_batch;
+    const int batch = launch_batch_size(H);
     auto launch_batch = [&](int nb) -> int32_t {
         nb = std::min(nb, max_pass - launched);
         for (int i = 0; i < nb; ++i) BH_TRY(launch_pass(launched + i));
         launched += nb;
         return BH_OK;
     };
+    // Same launch-ahead schedule and the same rank-independent exit predicate as pcg_run (mirror: status field = error
+    // flag, iter field = breakpoints, n_hmul = passes run).
+    auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
     BH_TRY(launch_batch(2));
-    BH_TRY(wait_mirror(c, a.tag, launched, &mw));       // mirror: status field = error flag, iter field = breakpoints
-    while (!mw.done && launched < max_pass) {
+    while (true) {
         const int target = launched;
-        (void)target;
-        BH_TRY(launch_batch(batch));
-        BH_TRY(wait_mirror(c, a.tag, launched, &mw));
+        const bool more = launched < max_pass;
+        if (more) BH_TRY(launch_batch(batch));
+        BH_TRY(wait_mirror(c, a.tag, target, &mw));
+        if (done_by(target) || !more) break;
     }
+    BH_TRY(wait_mirror(c, a.tag, launched, &mw));
     std::vector<int> mask((size_t)P->ldA, -1);
     BH_TRY(fetch_vec(s_out, c.w, n, false));
     BH_HIP(hipMemcpyAsync(mask.data(), P->fixrank, (size_t)P->ldA * sizeof(int), hipMemcpyDeviceToHost, s));
