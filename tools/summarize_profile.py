@@ -32,8 +32,12 @@ def main(tag):
             if r["Counter_Name"] == counter:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         for name, vals in acc.items():
-            pmc.setdefault(name, {})[counter + "_KiB_avg"] = sum(vals) / len(vals)
-            pmc[name][counter + "_dispatches"] = len(vals)
+            # a launch enqueued past the CG exit sees state->done and returns at once (a gated no-op, ~0 bytes): it is a
+            # dispatch of the same kernel symbol but not a launch of the operation, so it must not dilute the average
+            live = [v for v in vals if v >= 0.01 * max(vals)] if max(vals) > 0 else vals
+            pmc.setdefault(name, {})[counter + "_KiB_avg"] = sum(live) / len(live)
+            pmc[name][counter + "_dispatches"] = len(live)
+            pmc[name][counter + "_gated_dispatches_excluded"] = len(vals) - len(live)
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) + --kernel-trace, bench.py --steps 5",
            "correction": "HBM bytes per launch = 2*FETCH_SIZE*1024 (gfx950 half-count of 16-B/lane reads) + WRITE_SIZE*1024",
            "kernels": {}}
