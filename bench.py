@@ -250,7 +250,8 @@ def main():
         print(json.dumps(line), flush=True)
     barrier()
     if dist is not None:
-        bh._lib.lib().bh_comm_destroy()
+        H.close()                                   # handles first: the communicator cannot change under a live handle
+        bh._lib.check(bh._lib.lib().bh_comm_destroy(), "bh_comm_destroy")
         dist.destroy_process_group()
 
 

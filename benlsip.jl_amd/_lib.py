@@ -11,6 +11,8 @@ import numpy as np
 from . import build as _build
 
 BH_OK = 0
+BH_ERR_INVALID_ARG, BH_ERR_NOT_INIT, BH_ERR_HIP, BH_ERR_RCCL = -1, -2, -3, -4
+BH_ERR_PRECONDITION, BH_ERR_SHAPE, BH_ERR_NO_DEVICE, BH_ERR_UNSUPPORTED = -5, -6, -7, -8
 BH_FLAG_PROFILE = 1
 BH_UNIQUE_ID_BYTES = 128
 

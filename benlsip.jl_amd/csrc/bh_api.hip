@@ -67,6 +67,7 @@ struct Ctx {
     const char* (*p_ncclGetErrorString)(ncclResult_t) = nullptr;
     CgWorkspace cg;
     double* scratch_dev = nullptr;   // small device scratch (selftest, f2b)
+    int live_hess = 0;               // bh_hess handles alive (a handle bakes in this rank's share of C: see bh_comm_init)
 };
 
 Ctx g_ctx;
@@ -219,6 +220,7 @@ struct bh_hess {
     std::vector<hipEvent_t> ev;    // 2*kEvCap, created lazily
     std::vector<int> ev_pending;   // launch index (within the running bh_pcg) of each recorded pair
     uint64_t hmul_seq = 0;         // H*p launches of bh_pcg calls on this handle (profile sampling)
+    bool counted = false;          // included in g_ctx.live_hess (false while a create is failing)
 };
 
 struct bh_proj {
@@ -293,6 +295,13 @@ int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
         if ((++spins & 0xffff) == 0) {
             hipError_t q = hipStreamQuery(g_ctx.stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(BH_ERR_HIP, std::string("CG loop: ") + hipGetErrorString(q));
+            if (q == hipSuccess) {
+                // everything enqueued has run: the word is final.  Not reaching the target now is a logic error, not a wait.
+                const unsigned long long w2 = *c.h_mirror;
+                const bool ok = ((w2 >> 48) & 0xffffu) == (tag & 0xffffu) && ((((w2 >> 40) & 0xf) != 0) || (int)(w2 & 0xfffff) >= target);
+                if (!ok) return fail(BH_ERR_HIP, "internal: stream drained but the loop state did not reach the launch target");
+                continue;
+            }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
                 return fail(BH_ERR_HIP, "CG loop: no progress for 120 s");
         }
@@ -827,6 +836,8 @@ int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id_in) {
     // RCCL path (dlopen, ncclCommInitRank, ncclAllReduce on the library stream) can be exercised on a one-GPU box.
     const char* force = getenv("BH_FORCE_COMM");
     if (nranks == 1 && !(force && atoi(force) != 0)) { g_ctx.rank = 0; g_ctx.nranks = 1; return BH_OK; }
+    // a bh_hess bakes in which rank applies the replicated C rows (rank 0): the rank must not change under a live handle
+    if (g_ctx.live_hess > 0) return fail(BH_ERR_PRECONDITION, "bh_comm_init: destroy all bh_hess handles first (create them after the communicator)");
     if (!id_in) return fail(BH_ERR_INVALID_ARG, "NULL unique id");
     BH_TRY(load_rccl());
     ncclUniqueId id;
@@ -838,6 +849,7 @@ int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id_in) {
 }
 
 int32_t bh_comm_destroy(void) {
+    if (g_ctx.comm && g_ctx.live_hess > 0) return fail(BH_ERR_PRECONDITION, "bh_comm_destroy: destroy all bh_hess handles first");
     if (g_ctx.comm && g_ctx.p_ncclCommDestroy) {
         (void)hipStreamSynchronize(g_ctx.stream);
         g_ctx.p_ncclCommDestroy(g_ctx.comm);
@@ -869,6 +881,8 @@ int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     BH_TRY(sync_flush());
     *out = H;
+    H->counted = true;
+    g_ctx.live_hess += 1;
     return BH_OK;
 }
 
@@ -888,6 +902,8 @@ int32_t bh_hess_create_dev(bh_hess** out, const double* J_dev, int64_t d, int64_
     if (rc == BH_OK && hipStreamSynchronize(g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "bh_hess_create_dev: synchronize");
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     *out = H;
+    H->counted = true;
+    g_ctx.live_hess += 1;
     return BH_OK;
 }
 
@@ -914,6 +930,8 @@ int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t ro
     dev_free(cs_dev);
     if (e != hipSuccess) { bh_hess_destroy(H); return fail(BH_ERR_HIP, std::string("synth_fill: ") + hipGetErrorString(e)); }
     *out = H;
+    H->counted = true;
+    g_ctx.live_hess += 1;
     return BH_OK;
 }
 
@@ -925,6 +943,7 @@ int32_t bh_hess_set_mu(bh_hess* H, double mu) {
 
 int32_t bh_hess_destroy(bh_hess* H) {
     if (!H) return BH_OK;
+    if (H->counted) g_ctx.live_hess -= 1;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(H->Jd); dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf);
     dev_free(H->partials); dev_free(H->sq_partials); dev_free(H->scalar);
@@ -1084,7 +1103,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     }
     P->active_set = true;
     if (fix_chunks) {
-        // keep a copy with the bits beyond n cleared (Julia keeps them zero; be defensive)
+        // whole words are kept and compared (Julia keeps the bits beyond n zero; stray bits only ever cause a rebuild)
         P->last_chunks.assign(fix_chunks, fix_chunks + nwords);
     } else {
         P->last_chunks.assign(nwords, 0ull);
@@ -1152,8 +1171,6 @@ int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
 // ---- projected_cg ---------------------------------------------------------------------------
 struct PcgFin { int done, status, iter, n_hmul; };
 
-// Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
-// still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
 // How many iterations the host enqueues per launch-ahead batch.  One batch is always in flight while the host waits for
 // the one before it, so the GPU never idles as long as the host can enqueue a batch faster than the GPU runs one; every
 // iteration enqueued past the exit is a gated no-op that still costs ~1.5 us per kernel (measured, tools/dispatch_floor.py)
@@ -1168,6 +1185,8 @@ static int launch_batch_size(const bh_hess* H) {
 // an exact prediction means no gated launches and no host round trip inside the loop at all.
 constexpr int kFirstBatchCap = 32;
 
+// Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
+// still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
 static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* wlp, const double* wup, double* wp, bool w_in_ws,
                        double kappa2, double atol_negcurv, double atol_f2b, int64_t trace_cap, PcgFin* fin_out, double* hw = nullptr) {
     const int64_t n = H->n, n_pad = H->ld;

@@ -90,6 +90,10 @@ int32_t bh_device_info(char* name_out, int64_t name_cap, int32_t* n_cu, char* ar
 #define BH_UNIQUE_ID_BYTES 128
 /* rank 0 creates the id, the host runtime (torch.distributed, MPI, a Julia Distributed channel) broadcasts it. */
 int32_t bh_comm_unique_id(void* id_out /* BH_UNIQUE_ID_BYTES */);
+/* Both return BH_ERR_PRECONDITION while any bh_hess handle is alive: a handle records at creation whether THIS rank applies
+ * the replicated C rows (rank 0 does), so the rank must not change under it.  Order: bh_init, bh_comm_init, create handles,
+ * ..., destroy handles, bh_comm_destroy.  (nranks == 1 creates no communicator and is always accepted.)
+ * BH_RCCL_LIB (environment) names the librccl to load; default: the copy already mapped into the process, else the system one. */
 int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id /* BH_UNIQUE_ID_BYTES */);
 int32_t bh_comm_destroy(void);
 int32_t bh_comm_info(int32_t* rank, int32_t* nranks);

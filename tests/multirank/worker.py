@@ -83,7 +83,8 @@ def main():
     st = H.stats()
     out["n_allreduce"] = st["n_allreduce"]
     np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)
-    bh._lib.lib().bh_comm_destroy()
+    H.close()
+    bh._lib.check(bh._lib.lib().bh_comm_destroy(), "bh_comm_destroy")
     print("rank %d done: %d all-reduces" % (rank, st["n_allreduce"]), flush=True)
 
 

@@ -475,6 +475,12 @@ v = np.random.default_rng(1).standard_normal(300)
 H0 = bh.AlHessian(J, None, 1.0)
 a0, g0, s0 = H0 * v, H0.jtv(J @ v), bh.vthv(H0, v)
 if os.environ.get("BH_FORCE_COMM") == "1":
+    try:
+        bh.init_distributed(0, 1, lambda b: b)
+        raise SystemExit("bh_comm_init must refuse while a bh_hess is alive")
+    except bh.BenlsipHipError as e:
+        assert e.code == bh._lib.BH_ERR_PRECONDITION
+    H0.close()
     bh.init_distributed(0, 1, lambda b: b)
     r, n = bh._lib.C.c_int32(), bh._lib.C.c_int32()
     bh._lib.lib().bh_comm_info(bh._lib.C.byref(r), bh._lib.C.byref(n))
@@ -485,7 +491,9 @@ assert np.array_equal(a, a0) and np.array_equal(g, g0) and s == s0
 cons = bh.MixedConstraints(np.zeros((0, 300)))
 w, st, info = bh.projected_cg(g, H, np.full(300, -np.inf), np.full(300, np.inf), cons, 0.1, full_output=True)
 print("OK", H.stats()["n_allreduce"], info["n_hmul"])
-bh._lib.lib().bh_comm_destroy()
+assert bh._lib.lib().bh_comm_destroy() == bh._lib.BH_ERR_PRECONDITION      # refused while handles are alive
+H0.close(); H.close()
+assert bh._lib.lib().bh_comm_destroy() == 0
 """ % root
     env = dict(os.environ, BH_FORCE_COMM="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
