@@ -227,6 +227,16 @@ def main():
             "fused_ms": ms_f, "fused_gbs": st["bytes_per_hmul"] / ms_f / 1e6,
             "note": "back-to-back launches timed with hipEvents on the launch stream (bh_time_kernel), this rank's shard",
         }
+        # practical ceiling: a kernel that does nothing but read the same 2 GiB once (best of 1/2/4/8 workgroups per CU)
+        probe_ms = {1 << (k - 3): H.time_kernel(k, 10) for k in (3, 4, 5, 6)}
+        best_wg = min(probe_ms, key=probe_ms.get)
+        probe_gbs = 8.0 * d_loc * N_COLS / probe_ms[best_wg] / 1e6
+        line["read_probe"] = {
+            "gbs": probe_gbs, "ms": probe_ms[best_wg], "workgroups_per_cu": best_wg, "frac_of_peak": probe_gbs / HBM_PEAK_GBS,
+            "fused_kernel_vs_probe": (st["bytes_per_hmul"] / ms_f / 1e6) / probe_gbs,
+            "ms_by_workgroups_per_cu": probe_ms,
+            "note": "read_probe_kernel: 16-byte non-temporal loads + adds only, same J image; what a single-read kernel can reach here",
+        }
     if world == 1 and not args.no_extras and not args.no_ic_extra and args.variant == "wc":
         # steady-state CG iteration cost on the ill-conditioned variant (23 iterations per subproblem): outside the timed region
         # (the first handle stays allocated: freeing 2 GiB here makes the driver scrub it in the background, which took

@@ -1648,11 +1648,31 @@ int32_t bh_stats_reset(bh_hess* H) {
 
 int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
     BH_REQUIRE_INIT();
-    if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 2) return fail(BH_ERR_INVALID_ARG, "bad argument");
-    if (multi_panel(H)) return fail(BH_ERR_UNSUPPORTED, "bh_time_kernel: single-panel handles only (n <= 8192)");
+    if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 6) return fail(BH_ERR_INVALID_ARG, "bad argument");
     hipEvent_t e0, e1;
     BH_HIP(hipEventCreate(&e0));
     BH_HIP(hipEventCreate(&e1));
+    if (kind >= 3) {
+        // read-only stream probe over the (d + q) x ld image: 1, 2, 4 or 8 workgroups per CU
+        const int grid = g_ctx.n_cu * (1 << (kind - 3));
+        const int64_t nchunks_total = (H->d + H->q) * (H->ld / 2);
+        if (grid > H->g_cap * (int)H->ld) return fail(BH_ERR_UNSUPPORTED, "probe output does not fit the slab buffer");
+        double total = 0.0;
+        for (int i = -1; i < reps; ++i) {           // i = -1: warm-up
+            BH_HIP(hipEventRecord(e0, g_ctx.stream));
+            hipLaunchKernelGGL(read_probe_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->Jd, nchunks_total, H->partials);
+            BH_HIP(hipEventRecord(e1, g_ctx.stream));
+            BH_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            BH_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (i >= 0) total += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = total / reps;
+        return BH_OK;
+    }
+    if (multi_panel(H)) return fail(BH_ERR_UNSUPPORTED, "bh_time_kernel: single-panel handles only (n <= 8192)");
     const int cfg = pick_config(H->nchunks);
     RowStreamArgs a{};
     a.J = H->Jd; a.ld = H->ld; a.d_rows = H->d; a.nchunks = H->nchunks; a.mu = H->mu; a.state = nullptr;

@@ -294,4 +294,31 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(double* __restrict__ ds
     }
 }
 
+// Read-only stream probe: the practical HBM read ceiling on the SAME image the row-stream kernels sweep (bh_time_kernel
+// kinds 3..6).  Nothing but 16-byte non-temporal loads (8 independent ones in flight per lane) and one add per load; one
+// partial per workgroup is written so the loads cannot be elided.  What this kernel reaches is what any single-read
+// kernel can reach on this device; the fused kernel is quoted against it in bench.py ("read_probe").
+__global__ __launch_bounds__(256) void read_probe_kernel(const double* __restrict__ J, int64_t nchunks_total, double* __restrict__ out) {
+    __shared__ double scratch[256 / 64];
+    const dvec2* __restrict__ src = reinterpret_cast<const dvec2*>(J);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; c + 7 * stride < nchunks_total; c += 8 * stride) {
+        dvec2 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = __builtin_nontemporal_load(src + c + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += x[k].x + x[k].y;
+    }
+    for (; c < nchunks_total; c += stride) {
+        const dvec2 x = __builtin_nontemporal_load(src + c);
+        acc[0] += x.x + x.y;
+    }
+    double tot[1] = {((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))};
+    block_reduce<256, 1>(tot, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) out[blockIdx.x] = tot[0];
+}
+
+
 }  // namespace bh

@@ -139,7 +139,7 @@ class AlHessian:
         check(_lib.lib().bh_stats_reset(self._h), "bh_stats_reset")
 
     def time_kernel(self, kind, reps=20):
-        """Average hipEvent milliseconds of one launch: kind 0 = fused J'(Jp), 1 = J v, 2 = J'u."""
+        """Average hipEvent milliseconds of one launch: kind 0 = fused J'(Jp), 1 = J v, 2 = J'u, 3..6 = read-only stream probe with 1/2/4/8 workgroups per CU."""
         ms = ct.c_double(0.0)
         check(_lib.lib().bh_time_kernel(self._h, kind, reps, ct.byref(ms)), "bh_time_kernel")
         return ms.value

@@ -212,7 +212,9 @@ int32_t bh_stats_reset(bh_hess* H);
 /* Tuning knobs (kernel geometry, CG launch-ahead depth); unknown keys return BH_ERR_INVALID_ARG. */
 int32_t bh_set_option(const char* key, int64_t value);
 /* Time `reps` back-to-back launches of one kernel class with hipEvents on the launch stream.
- * kind: 0 = fused J'(Jp), 1 = J·v, 2 = J'·u.  Returns the average milliseconds per launch. */
+ * kind: 0 = fused J'(Jp), 1 = J·v, 2 = J'·u; 3..6 = read-only stream probe over the same image (nothing but 16-byte
+ * non-temporal loads and adds) with 1, 2, 4, 8 workgroups per CU: the practical single-read ceiling the kernels are
+ * quoted against.  Returns the average milliseconds per launch. */
 int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms);
 /* Device self-test of the wave64 DPP/permlane reduction network (sum and NaN-propagating min). */
 int32_t bh_selftest(void);

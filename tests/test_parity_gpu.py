@@ -60,6 +60,21 @@ def test_matvec_is_deterministic(bh):
     H.close()
 
 
+def test_kernel_timers_and_read_probe(bh):
+    """bh_time_kernel: the three row-stream classes and the read-only stream probe (kinds 3..6) run on any shape and return
+    a positive time; the probe must not disturb the handle (its output lands in the slab buffer the next product rewrites)."""
+    rng = np.random.default_rng(5)
+    J = rng.standard_normal((777, 130))
+    H = bh.AlHessian(J, rng.standard_normal((2, 130)), 3.0)
+    v = rng.standard_normal(130)
+    before = H * v
+    for kind in range(7):
+        assert H.time_kernel(kind, 2) > 0.0
+    with pytest.raises(bh.BenlsipHipError):
+        H.time_kernel(7, 1)
+    assert np.array_equal(H * v, before)
+
+
 def test_linearity_and_symmetry_at_full_size(bh):
     """Size-independent properties at BASELINE config 3 (d=65536, n=4096; J generated in HBM):
     H(av+bw) = aHv + bHw, v'Hw = w'Hv, v'Hv = vthv(H,v) = ||Jv||^2, and J rows check against the host generator."""
