@@ -58,3 +58,82 @@ def test_fuzz_projected_cg_against_c_oracle(bh, seed):
         cons.close()
     lib.bh_set_option(b"proj_form", 1)
     assert not mism, "\n".join(str(m) for m in mism)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_cauchy_step_and_minor_iterate(bh, seed):
+    """Randomised small instances of the two device-resident callers against the NumPy oracle:
+    cauchy_step (same breakpoint count, same final active set, same step) and minor_iterate (same CG exit, same step)."""
+    rng = np.random.default_rng(7000 + seed)
+    lib = bh._lib.lib()
+    mism = []
+    for case in range(25):
+        n = int(rng.integers(3, 70))
+        d = int(rng.integers(2 * n, 4 * n + 2))
+        mA = int(rng.integers(0, min(3, n - 2) + 1)) if rng.random() < 0.5 else 0
+        lib.bh_set_option(b"chol_downdate", int(rng.integers(0, 2)))
+        J = rng.standard_normal((d, n)) / np.sqrt(d)
+        A = rng.standard_normal((mA, n))
+        L0 = R.chol_lower(A @ A.T)
+        xlow, xupp = -np.ones(n), np.ones(n)
+        nact = int(rng.integers(0, max(1, (n - mA) // 3)))
+        x = np.clip(0.5 * rng.standard_normal(n), -0.95, 0.95)
+        act = rng.choice(n, nact, replace=False)
+        x[act] = np.where(rng.random(nact) < 0.5, -1.0, 1.0)
+        g = rng.standard_normal(n)
+        delta = float(rng.choice([0.1, 0.5, 3.0])) * 0.1 * np.linalg.norm(g)
+        mu = 2.0
+        Ho = R.AlHessian(J, np.zeros((0, n)), mu)
+        H = bh.AlHessian(J, None, mu)
+
+        # ---- cauchy_step
+        cons_o = R.make_mixed_constraints(A, L0, l=xlow, u=xupp)
+        count = [0]
+
+        class Ops(R.NumpyOps):
+            def hmul(self, Hh, v):
+                count[0] += 1
+                return R.hmul(Hh, v)
+        try:
+            s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, Ops())
+        except Exception:
+            s_ref = None              # the reference itself fails here (no breakpoint left / factor lost definiteness)
+        cons = bh.MixedConstraints(A, None, l=xlow, u=xupp)
+        if s_ref is None:
+            with pytest.raises(bh.BenlsipHipError):
+                bh.cauchy_step(x, g, H, cons, delta)
+        else:
+            s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+            ok = np.array_equal(cons.fixvars, cons_o.fixvars) and info["n_hmul"] == count[0] and \
+                np.linalg.norm(s - s_ref) <= 1e-8 * max(np.linalg.norm(s_ref), 1e-300)
+            if not ok:
+                # a branch scalar within rounding of its threshold?  The oracle on a 1e-14-perturbed J tells.
+                cons_p = R.make_mixed_constraints(A, L0, l=xlow, u=xupp)
+                s_p = R.cauchy_step(x, g, R.AlHessian(J * (1 + 1e-14 * rng.standard_normal(J.shape)), np.zeros((0, n)), mu), L0, cons_p,
+                                    delta, R.NumpyOps())
+                if np.array_equal(cons_p.fixvars, cons_o.fixvars) and np.linalg.norm(s_p - s_ref) <= 1e-9 * max(np.linalg.norm(s_ref), 1e-300):
+                    mism.append(("cauchy", case, n, d, mA, nact, delta, info, count[0], int(np.sum(cons.fixvars != cons_o.fixvars)),
+                                 float(np.linalg.norm(s - s_ref))))
+
+        # ---- minor_iterate from the same point (fresh constraint objects: active set = the bounds x sits on)
+        fix = np.zeros(n, dtype=bool)
+        fix[act] = True
+        if mA + nact < n:
+            mo = R.make_mixed_constraints(A, L0, fix if nact else None, l=xlow, u=xupp)
+            mc = bh.MixedConstraints(A, None, fix, l=xlow, u=xupp)
+            s0 = np.zeros(n)
+            kappa2 = float(rng.choice([0.1, 1e-2]))
+            w_ref, st_ref = R.minor_iterate(x, s0, g, Ho, mo, delta, kappa2)
+            w, st, info = bh.minor_iterate(x, s0, g, H, mc, delta, kappa2, full_output=True)
+            ok = int(st) == int(st_ref) and (not np.all(np.isfinite(w_ref)) or relnorm(w, w_ref) <= 1e-6)
+            if not ok:
+                Hp = R.AlHessian(J * (1 + 1e-14 * rng.standard_normal(J.shape)), np.zeros((0, n)), mu)
+                w_p, st_p = R.minor_iterate(x, s0, g, Hp, mo, delta, kappa2)
+                stable = int(st_p) == int(st_ref) and (not np.all(np.isfinite(w_ref)) or relnorm(w_p, w_ref) <= 1e-8)
+                if stable:
+                    mism.append(("minor", case, n, d, mA, nact, kappa2, int(st), int(st_ref), relnorm(w, w_ref)))
+            mc.close()
+        cons.close()
+        H.close()
+    lib.bh_set_option(b"chol_downdate", 1)
+    assert not mism, "\n".join(str(m) for m in mism)
