@@ -133,8 +133,9 @@ const RsConfig kRsConfigs[] = {
     {256, 8, 4, 2},    // 11: variant 6 = one register buffer (no prefetch), 2 WGs/CU
     {256, 8, 3, 1},    // 12: variant 7 = R = 3 with prefetch
     {256, 8, 6, 1},    // 13: variant 8 = R = 6, one register buffer
+    {512, 16, 1, 1},   // 14: nchunks <= 8192 (n <= 16384): one row per step; the fused mode parks v in LDS (VL)
 };
-constexpr int64_t kMaxChunks = 4096;
+constexpr int64_t kMaxChunks = 8192;
 
 int pick_config(int nchunks) {
     if (nchunks <= 64) return 0;
@@ -154,7 +155,8 @@ int pick_config(int nchunks) {
             default: return 4;
         }
     }
-    return 5;
+    if (nchunks <= 4096) return 5;
+    return 14;
 }
 
 template <int T, int CPT, int R, int NT = 1, int PF = 1>
@@ -164,6 +166,21 @@ void launch_rs_mode(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
         case MODE_JTV: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_JTV, NT, PF>), dim3(grid), dim3(T), 0, s, a); break;
         default: hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, NT, PF>), dim3(grid), dim3(T), 0, s, a); break;
     }
+}
+
+// n <= 16384: J v and J'u keep everything in registers; the fused mode needs the v slice in LDS (T * CPT * 16 bytes = 128 KiB,
+// above the 64 KiB a kernel may use without asking).
+template <int T, int CPT, int R>
+void launch_rs_mode_vlds(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
+    if (mode != MODE_FUSED) { launch_rs_mode<T, CPT, R>(mode, a, grid, s); return; }
+    constexpr size_t lds = (size_t)T * CPT * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 1>), dim3(grid), dim3(T), lds, s, a);
 }
 
 void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
@@ -181,6 +198,7 @@ void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipS
         case 11: launch_rs_mode<256, 8, 4, 1, 0>(mode, a, grid, s); break;
         case 12: launch_rs_mode<256, 8, 3, 1, 1>(mode, a, grid, s); break;
         case 13: launch_rs_mode<256, 8, 6, 1, 0>(mode, a, grid, s); break;
+        case 14: launch_rs_mode_vlds<512, 16, 1>(mode, a, grid, s); break;
         default: launch_rs_mode<512, 4, 2>(mode, a, grid, s); break;
     }
 }
@@ -210,7 +228,7 @@ struct bh_hess {
     double* vpad = nullptr;        // ld
     double* zpad = nullptr;        // ld
     double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
-    double* tbuf = nullptr;        // d + q   (t = J v between the two passes of a column-panel H*p; NULL for n <= 8192)
+    double* tbuf = nullptr;        // d + q   (t = J v between the two passes of a column-panel H*p; NULL for n <= 16384)
     double* partials = nullptr;    // g_cap x ld
     double* sq_partials = nullptr; // g_cap
     double* scalar = nullptr;      // 2
@@ -1672,7 +1690,7 @@ int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
         *avg_ms = total / reps;
         return BH_OK;
     }
-    if (multi_panel(H)) return fail(BH_ERR_UNSUPPORTED, "bh_time_kernel: single-panel handles only (n <= 8192)");
+    if (multi_panel(H)) return fail(BH_ERR_UNSUPPORTED, "bh_time_kernel: single-panel handles only (n <= 16384)");
     const int cfg = pick_config(H->nchunks);
     RowStreamArgs a{};
     a.J = H->Jd; a.ld = H->ld; a.d_rows = H->d; a.nchunks = H->nchunks; a.mu = H->mu; a.state = nullptr;

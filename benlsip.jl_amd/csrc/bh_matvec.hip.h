@@ -39,11 +39,15 @@ struct RowStreamArgs {
 // NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
 // PF: 1 = issue the next row group's loads before reducing the current one (two register buffers); 0 = one buffer, latency
 // hidden by several co-resident workgroups instead.
-template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1>
+// VL: 1 = each lane parks its slice of v in LDS (dynamic, nchunks x 16 bytes, lane-private slots: no barrier, no bank
+// conflicts) instead of registers.  For 8192 < n <= 16384 the two row buffers and the z accumulators of the fused mode
+// fill the register file on their own; the 128 KiB of LDS a CU has left over hold v.
+template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1, int VL = 0>
 __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     if (a.state != nullptr && a.state->done) return;
     constexpr int NW = T / 64;
     __shared__ double red[2][R][NW];
+    extern __shared__ __attribute__((aligned(16))) double2 v_lds[];     // VL only: [CPT][T]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t ld2 = a.ld >> 1;   // row stride in double2
@@ -66,6 +70,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
             }
         }
+        if (VL && MODE != MODE_JTV) v_lds[k * T + tid] = vv[k];      // read back only by this lane
     }
 
     const int64_t ngroups = (a.nrows + R - 1) / R;
@@ -106,8 +111,9 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
-                    acc = fma(X[r][k].x, vv[k].x, acc);
-                    acc = fma(X[r][k].y, vv[k].y, acc);
+                    const double2 vk = VL ? v_lds[k * T + tid] : vv[k];
+                    acc = fma(X[r][k].x, vk.x, acc);
+                    acc = fma(X[r][k].y, vk.y, acc);
                 }
                 s[r] = wave_sum(acc);
             }

@@ -647,10 +647,11 @@ def test_cauchy_step_parity(bh, chol_downdate, d, n, mA, nact, delta_scale, seed
     assert np.linalg.norm(bh.projection(cons, r) - R.projection(cons_o, r)) <= 1e-10 * np.linalg.norm(r)
 
 
-# ----------------------------------------------------------------------------- wide J (column panels, n > 8192)
-@pytest.mark.parametrize("d,n,q", [(70, 8200, 1), (40, 10001, 0), (33, 20000, 2)])
+# ----------------------------------------------------------------------------- wide J (n > 8192)
+@pytest.mark.parametrize("d,n,q", [(70, 8200, 1), (40, 10001, 0), (29, 16384, 1), (31, 16385, 0), (33, 20000, 2)])
 def test_wide_jacobian_column_panels(bh, d, n, q):
-    """n > 8192: rows no longer fit one workgroup's registers; J is swept in 4096-column panels (two-pass H*p)."""
+    """8192 < n <= 16384: one row per step, the fused kernel parks its slice of v in LDS (still a single read of J);
+    n > 16384: J is swept in 4096-column panels (two-pass H*p).  CG runs on the generic n-vector kernels in both."""
     rng = np.random.default_rng(n)
     J, C, mu = rng.standard_normal((d, n)), rng.standard_normal((q, n)), 0.5
     v, u = rng.standard_normal(n), rng.standard_normal(d)
