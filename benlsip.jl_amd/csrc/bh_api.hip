@@ -673,7 +673,24 @@ void launch_cg_first_step(const CgArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL((cg_step_reg_kernel<4, 0, true>), dim3(1), dim3(CG_T), 0, s, a);
 }
 
-size_t trsv_lds_bytes(int m) { return ((size_t)((m + 1) & ~1) + 64 * 65) * sizeof(double); }
+// LDS of trsv_pair_kernel: x[m2] | tile[64*65] | part[4*m2] (only when the split trailing update fits the 160 KiB of a CU)
+constexpr size_t kLdsPerCu = 160 * 1024;
+int trsv_split_for(int m) {
+    const size_t m2 = (size_t)((m + 1) & ~1);
+    return (5 * m2 + 64 * 65) * sizeof(double) <= kLdsPerCu ? 4 : 1;
+}
+// The dynamic-LDS ceiling of the kernel is a property of the function, shared by every handle: only ever raise it.
+int32_t ensure_trsv_lds(size_t lds) {
+    static size_t granted = 0;
+    if (lds <= granted) return BH_OK;
+    BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    granted = lds;
+    return BH_OK;
+}
+size_t trsv_lds_bytes(int m) {
+    const size_t m2 = (size_t)((m + 1) & ~1);
+    return ((trsv_split_for(m) == 4 ? 5 : 1) * m2 + 64 * 65) * sizeof(double);
+}
 
 // v_out = P(r_pad): r_pad is a zero-padded ldA-length device vector, v_out has >= n entries.
 int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgState* st, bool device_mask = false) {
@@ -690,9 +707,10 @@ int32_t launch_project(bh_proj* P, const double* r_pad, double* v_out, const CgS
     const int grid1 = a.mA + (a.reduced ? 0 : (a.nfix + 255) / 256);
     hipLaunchKernelGGL(proj_left_mul_kernel, dim3(grid1), dim3(256), 0, g_ctx.stream, a, r_pad);
     if (a.reduced && a.mpp <= 64) hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, g_ctx.stream, a);
-    else hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), trsv_lds_bytes(a.mpp), g_ctx.stream, a);
+    else hipLaunchKernelGGL(trsv_pair_kernel, dim3(1), dim3(CG_T), trsv_lds_bytes(a.mpp), g_ctx.stream, a, trsv_split_for(a.mpp));
     const int nch = (n + 1) / 2;
-    hipLaunchKernelGGL((proj_left_mul_tr_kernel<true>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
+    if (a.mA <= 64) hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 4>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a, r_pad, v_out);
+    else hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 16>), dim3((nch + 63) / 64), dim3(1024), 0, g_ctx.stream, a, r_pad, v_out);
     BH_HIP(hipGetLastError());
     return BH_OK;
 }
@@ -1099,8 +1117,8 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
             }
         }
         const size_t lds = trsv_lds_bytes(reduced ? (int)P->mA : (int)want);
-        if (lds > 160 * 1024) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
-        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > kLdsPerCu) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
+        BH_TRY(ensure_trsv_lds(lds));
     } else if (mpp != want && L != nullptr) {
         return fail(BH_ERR_SHAPE, "mpp != count(fixvars) for mA == 0");
     }
@@ -1178,7 +1196,7 @@ int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
     BH_TRY(stage_vec(P->tw, y, P->mA + P->nfix, false));
     ProjArgs a = proj_args(P, nullptr, false);
     const int nch = ((int)P->n + 1) / 2;
-    hipLaunchKernelGGL((proj_left_mul_tr_kernel<false>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a,
+    hipLaunchKernelGGL((proj_left_mul_tr_kernel<false, 4>), dim3((nch + 63) / 64), dim3(256), 0, g_ctx.stream, a,
                        (const double*)nullptr, P->vtmp);
     BH_HIP(hipGetLastError());
     BH_TRY(fetch_vec(out_n, P->vtmp, P->n, false));
@@ -1514,8 +1532,8 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     if (mA > 0) {
         BH_TRY(ensure_reduced_buffers(P));
         const size_t lds = trsv_lds_bytes(mA);
-        if (lds > 160 * 1024) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
-        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > kLdsPerCu) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
+        BH_TRY(ensure_trsv_lds(lds));
     }
     BH_TRY(stage_vec(c.x, x, n, false));
     BH_TRY(stage_vec(c.g, g, n, false));

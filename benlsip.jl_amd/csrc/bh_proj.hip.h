@@ -67,11 +67,13 @@ __global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const do
 }
 
 // out = r - left_mul_tr(tw)   (:72-84, :116, :134);  with SUBTRACT=false: out = left_mul_tr(tw).
-// Block = 64 chunks x 4 row groups (rows i = rg, rg+4, ...), combined through LDS in fixed order; grid = ceil(nch/64).
-template <bool SUBTRACT>
-__global__ __launch_bounds__(256) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
+// Block = 64 chunks x RG row groups (rows i = rg, rg+RG, ...), combined through LDS in fixed order; grid = ceil(nch/64).
+// RG = 4 (256 threads) up to 64 rows, RG = 16 (1024 threads) above: the grid is only nch/64 workgroups, so many rows per
+// thread serialise (33.8 us at mA = 512 with RG = 4).
+template <bool SUBTRACT, int RG>
+__global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
     if (proj_skip(a.state)) return;
-    __shared__ double2 sm[4][64];
+    __shared__ double2 sm[RG][64];
     const int nch = (a.n + 1) >> 1;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void proj_left_mul_tr_kernel(ProjArgs a, const
     if (c < nch) {
         const double2* A2 = reinterpret_cast<const double2*>(a.A);
         const int64_t ld2 = a.ldA >> 1;
-        for (int i = rg; i < a.mA; i += 4) {
+        for (int i = rg; i < a.mA; i += RG) {
             const double wi = a.tw[i];
             const double2 av = A2[(int64_t)i * ld2 + c];
             acc.x = fma(wi, av.x, acc.x);
@@ -89,8 +91,14 @@ __global__ __launch_bounds__(256) void proj_left_mul_tr_kernel(ProjArgs a, const
     sm[rg][cl] = acc;
     __syncthreads();
     if (rg != 0 || c >= nch) return;
-    acc.x = (sm[0][cl].x + sm[1][cl].x) + (sm[2][cl].x + sm[3][cl].x);
-    acc.y = (sm[0][cl].y + sm[1][cl].y) + (sm[2][cl].y + sm[3][cl].y);
+    acc = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int g4 = 0; g4 < RG; g4 += 4) {         // groups of four, each combined as (0+1)+(2+3), then added in order
+        const double qx = (sm[g4][cl].x + sm[g4 + 1][cl].x) + (sm[g4 + 2][cl].x + sm[g4 + 3][cl].x);
+        const double qy = (sm[g4][cl].y + sm[g4 + 1][cl].y) + (sm[g4 + 2][cl].y + sm[g4 + 3][cl].y);
+        acc.x = (g4 == 0) ? qx : acc.x + qx;
+        acc.y = (g4 == 0) ? qy : acc.y + qy;
+    }
     const int j0 = 2 * c, j1 = 2 * c + 1;
     int k0 = -1, k1 = -1;
     if (a.fixrank != nullptr) { k0 = a.fixrank[j0]; if (j1 < a.n) k1 = a.fixrank[j1]; }
@@ -486,89 +494,137 @@ __global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
     if (lane < m) a.tw[lane] = xi;
 }
 
-// tw <- L' \ (L \ tw)   (:114-115, :132-133).  Single workgroup, 64-wide blocked substitution;
-// the diagonal block is staged through LDS (coalesced column reads, conflict-free padded tile) and
-// solved by one wave with v_readlane broadcasts; trailing updates use all 16 waves.
-// Dynamic LDS: mpp doubles (the vector) + 64*65 doubles (tile).
-__global__ __launch_bounds__(CG_T) void trsv_pair_kernel(ProjArgs a) {
+// tw <- L' \ (L \ tw)   (:114-115, :132-133).  Single workgroup, 64-wide blocked substitution.
+//  * diagonal block: staged through LDS (padded tile, conflict-free row- and column-wise), solved by wave 0 with
+//    v_readlane broadcasts; the reciprocals of its diagonal are formed by all lanes at once BEFORE the dependent chain
+//    (one multiply per step in the chain instead of a division);
+//  * forward trailing update x[i] -= sum_jj L[i, j0+jj] x[j0+jj]: the 64 columns are split into SPLIT slices so that
+//    SPLIT x (rows left) threads work, partial sums combined in a fixed order (SPLIT = 4 when the LDS holds the partials,
+//    else 1);
+//  * backward update x[j0+c] -= sum_{k >= j0+nb} L[k, j0+c] x[k]: all 64 columns at once, 16 lanes per column
+//    (contiguous 128-byte pieces of the column), combined by a 16-lane butterfly;
+//  * the next diagonal tile is loaded into registers before the trailing update and written to LDS after it, so its
+//    latency overlaps the update.
+// Dynamic LDS: x[m2] | tile[64*65] | part[SPLIT == 4 ? 4*m2 : 0]   (m2 = m rounded up to even).
+__global__ __launch_bounds__(CG_T) void trsv_pair_kernel(ProjArgs a, int split) {
     if (proj_skip(a.state)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int m = a.mpp;
+    const int m2 = (m + 1) & ~1;
     double* x = smem;
-    double* tile = smem + ((m + 1) & ~1);    // [64][65]
+    double* tile = smem + m2;                // [64][65]
+    double* part = tile + 64 * 65;           // [4][m2] when split == 4
     const double* __restrict__ L = a.L;
     const int64_t ld = m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (m + 63) / 64;
+
+    double treg[4];
+    auto tile_fetch = [&](int j0) {          // 4096 entries, 4 per thread; zero outside the lower triangle / the block
+        const int nb = min(64, m - j0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * CG_T, rr = e & 63, cc = e >> 6;
+            treg[q] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
+        }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + q * CG_T, rr = e & 63, cc = e >> 6;
+            tile[rr * 65 + cc] = treg[q];
+        }
+    };
 
     for (int i = tid; i < m; i += CG_T) x[i] = a.tw[i];
+    tile_fetch(0);
+    tile_store();
     __syncthreads();
 
     // ---- forward: L y = t ----
-    for (int j0 = 0; j0 < m; j0 += 64) {
+    for (int b = 0; b < nblk; ++b) {
+        const int j0 = b * 64;
         const int nb = min(64, m - j0);
-        for (int e = tid; e < 64 * 64; e += CG_T) {
-            const int rr = e & 63, cc = e >> 6;
-            tile[rr * 65 + cc] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
-        }
-        __syncthreads();
         if (wave == 0) {
-            // lane i owns unknown j0+i; column jj of the block is tile[i*65 + jj] (conflict-free: stride 65)
+            // lane i owns unknown j0+i; column jj of the block is tile[i*65 + jj]
+            const double dii = tile[lane * 65 + lane];
+            const double di = (lane < nb) ? 1.0 / dii : 0.0;
             double xi = (lane < nb) ? x[j0 + lane] : 0.0;
 #pragma unroll 8
             for (int jj = 0; jj < nb; ++jj) {
-                const double ljj = tile[jj * 65 + jj];
                 const double lij = tile[lane * 65 + jj];
-                const double xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
+                if (lane == jj) xi = xi * di;
+                const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
                                                    __builtin_amdgcn_readlane(__double2loint(xi), jj));
-                const double xj = xs / ljj;
-                if (lane == jj) xi = xj;
-                else if (lane > jj) xi = fma(-lij, xj, xi);
+                if (lane > jj) xi = fma(-lij, xj, xi);
             }
             if (lane < nb) x[j0 + lane] = xi;
         }
-        __syncthreads();
-        for (int i = j0 + nb + tid; i < m; i += CG_T) {
-            double acc = 0.0;
-            for (int jj = 0; jj < nb; ++jj) acc = fma(L[i + (int64_t)(j0 + jj) * ld], x[j0 + jj], acc);
-            x[i] -= acc;
+        __syncthreads();                     // x[j0 .. j0+nb) final; wave 0 is done with the tile
+        const int i0 = j0 + nb, rem = m - i0;
+        if (b + 1 < nblk) tile_fetch(i0);    // in flight during the update
+        if (rem > 0) {
+            if (split == 4) {
+                const int per = (nb + 3) >> 2;
+                for (int w = tid; w < 4 * rem; w += CG_T) {
+                    const int q = w / rem, i = i0 + (w - q * rem);
+                    const int jlo = q * per, jhi = min(nb, jlo + per);
+                    double acc = 0.0;
+#pragma unroll 8
+                    for (int jj = jlo; jj < jhi; ++jj) acc = fma(L[i + (int64_t)(j0 + jj) * ld], x[j0 + jj], acc);
+                    part[q * m2 + i] = acc;
+                }
+                __syncthreads();
+                for (int i = i0 + tid; i < m; i += CG_T)
+                    x[i] -= (part[i] + part[m2 + i]) + (part[2 * m2 + i] + part[3 * m2 + i]);
+            } else {
+                for (int i = i0 + tid; i < m; i += CG_T) {
+                    double acc = 0.0;
+                    for (int jj = 0; jj < nb; ++jj) acc = fma(L[i + (int64_t)(j0 + jj) * ld], x[j0 + jj], acc);
+                    x[i] -= acc;
+                }
+            }
         }
+        if (b + 1 < nblk) tile_store();
         __syncthreads();
     }
 
-    // ---- backward: L' w = y ----
-    const int nblk = (m + 63) / 64;
+    // ---- backward: L' w = y ----   (the tile in LDS is the LAST diagonal block: exactly what the first step needs)
     for (int b = nblk - 1; b >= 0; --b) {
         const int j0 = b * 64;
         const int nb = min(64, m - j0);
-        // x[j0+c] -= sum_{k >= j0+nb} L[k, j0+c] * x[k]   (column segments are contiguous: wave per column)
-        for (int c = wave; c < nb; c += CG_T / 64) {
-            double acc = 0.0;
-            const double* col = L + (int64_t)(j0 + c) * ld;
-            for (int k = j0 + nb + lane; k < m; k += 64) acc = fma(col[k], x[k], acc);
-            acc = wave_sum(acc);
-            if (lane == 0) x[j0 + c] -= acc;
-        }
-        for (int e = tid; e < 64 * 64; e += CG_T) {
-            const int rr = e & 63, cc = e >> 6;
-            tile[rr * 65 + cc] = (rr < nb && cc < nb && rr >= cc) ? L[(j0 + rr) + (int64_t)(j0 + cc) * ld] : 0.0;
-        }
-        __syncthreads();
         if (wave == 0) {
             // lane i owns unknown j0+i and needs L[jj, i] for jj > i: tile[jj*65 + i] (consecutive lanes, conflict-free)
+            const double dii = tile[lane * 65 + lane];
+            const double di = (lane < nb) ? 1.0 / dii : 0.0;
             double xi = (lane < nb) ? x[j0 + lane] : 0.0;
 #pragma unroll 8
             for (int jj = nb - 1; jj >= 0; --jj) {
-                const double ljj = tile[jj * 65 + jj];
                 const double lji = tile[jj * 65 + lane];
-                const double xs = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
+                if (lane == jj) xi = xi * di;
+                const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xi), jj),
                                                    __builtin_amdgcn_readlane(__double2loint(xi), jj));
-                const double xj = xs / ljj;
-                if (lane == jj) xi = xj;
-                else if (lane < jj) xi = fma(-lji, xj, xi);
+                if (lane < jj) xi = fma(-lji, xj, xi);
             }
             if (lane < nb) x[j0 + lane] = xi;
         }
         __syncthreads();
+        if (b > 0) {
+            // the block above: its 64 columns each need sum_{k >= j0} L[k, c] x[k]  (everything below it is final now)
+            const int p0 = j0 - 64;
+            tile_fetch(p0);
+            const int c = tid >> 4, ks = tid & 15;          // 64 columns x 16 lanes
+            double acc = 0.0;
+            const double* col = L + (int64_t)(p0 + c) * ld;
+#pragma unroll 8
+            for (int k = j0 + ks; k < m; k += 16) acc = fma(col[k], x[k], acc);
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
+            __syncthreads();                 // every thread has read x before lane 0 of each group updates it
+            if (ks == 0) x[p0 + c] -= acc;
+            tile_store();
+            __syncthreads();
+        }
     }
 
     for (int i = tid; i < m; i += CG_T) a.tw[i] = x[i];

@@ -129,11 +129,14 @@ def proj_form(request, bh):
 
 
 @pytest.mark.parametrize("n,mA,nfix", [(6, 3, 3), (7, 3, 0), (40, 5, 10), (300, 20, 150), (300, 20, 0), (130, 64, 66), (1000, 64, 512),
-                                       (513, 1, 1), (64, 0, 9), (64, 0, 0), (4096, 64, 512), (700, 130, 200)])
+                                       (513, 1, 1), (64, 0, 9), (64, 0, 0), (4096, 64, 512), (700, 130, 200), (900, 65, 3), (1200, 257, 300),
+                                       (3500, 2, 3400)])
 def test_projection_parity(bh, proj_form, n, mA, nfix):
     """projection_nullspace! / projection_subspace! (src/polyhedral_constraints.jl:104-136) incl. garbage in the unread
     upper triangle of the factor.  Tolerance: a normal-equations projector is accurate to
-    ~eps*cond(B B') with B = [A; I_fix]; 1e-11*||r|| floor, 200*eps*cond above it (only (130,64,66), mpp == n, needs it)."""
+    ~eps*cond(B B') with B = [A; I_fix]; 1e-11*||r|| floor, 200*eps*cond above it (only (130,64,66), mpp == n, needs it).
+    Factor orders: <= 64 (one-wave solve), 65 / 130 / 257 (blocked solve, partial last block), 557 / 576 (augmented form, split
+    trailing update) and 3402 (augmented form, too large for the split: single-slice update)."""
     rng = np.random.default_rng(n + 7 * mA + nfix)
     A = rng.standard_normal((mA, n))
     L0 = R.chol_lower(A @ A.T)
