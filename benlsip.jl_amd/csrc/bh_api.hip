@@ -608,6 +608,12 @@ int32_t launch_chol(bh_proj* P, const CgState* gate) {
         return BH_OK;
     }
     double* dinv = P->Lr + (int64_t)mA * mA;      // scratch for the current panel's reciprocal diagonal (mA extra doubles)
+    static bool trsm_lds_granted = false;          // 97 KiB of dynamic LDS: above what a kernel may use without asking
+    if (!trsm_lds_granted) {
+        BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)kTrsmLdsBytes));
+        trsm_lds_granted = true;
+    }
     hipLaunchKernelGGL(copy_lower_kernel, dim3(std::min(1024, (mA * mA + 255) / 256)), dim3(256), 0, s, (const double*)P->M, P->Lr, mA,
                        P->info, gate);
     for (int k0 = 0; k0 < mA; k0 += 64) {
@@ -617,7 +623,8 @@ int32_t launch_chol(bh_proj* P, const CgState* gate) {
                            k0, 0, gate);
         const int rem = mA - k0 - nb;
         if (rem > 0) {
-            hipLaunchKernelGGL(chol_trsm_kernel, dim3((rem + 255) / 256), dim3(256), 0, s, P->Lr, mA, k0, nb, (const double*)dinv, gate);
+            hipLaunchKernelGGL(chol_trsm_kernel, dim3((rem + TRSM_T - 1) / TRSM_T), dim3(TRSM_T), kTrsmLdsBytes, s, P->Lr, mA, k0, nb,
+                               (const double*)dinv, gate);
             const int nt = (rem + 15) / 16;
             hipLaunchKernelGGL(chol_syrk_kernel, dim3(nt, nt), dim3(256), 0, s, P->Lr, mA, k0, nb, gate);
         }
