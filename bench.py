@@ -139,10 +139,19 @@ def main():
 
     import torch
     dist = None
+    # BH_BENCH_REHEARSAL=1: run the N > 1 code path on a ONE-GPU box — every rank on device 0, torch over gloo, the
+    # library's all-reduce through the host-staged stand-in (BH_RCCL_LIB, tests/multirank/) — to exercise this script's
+    # multi-rank flow (shards, replica check, teardown).  Its numbers mean nothing and are labelled as such.
+    rehearsal = os.environ.get("BH_BENCH_REHEARSAL", "0") not in ("", "0")
+    if rehearsal:
+        local_rank = 0
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import benlsip_jl_amd as bh
     bh.init(local_rank, flags=bh._lib.BH_FLAG_PROFILE)
@@ -194,7 +203,8 @@ def main():
         "value": world * args.steps / elapsed,
         "unit": "PCG subproblems/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on one GPU (all ranks share device 0, host-staged all-reduce): not a measurement",
         "config": {
             "workload": "BASELINE config 3 per GPU: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), box bounds, "
                         "p=512 active, mu=10, kappa2=0.1, variant=%s; one step = one projected_cg subproblem (bh_pcg_dev), "
