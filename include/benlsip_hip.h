@@ -209,7 +209,19 @@ int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes);
 int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes);
 int32_t bh_stats(bh_hess* H, bh_stats_t* out);
 int32_t bh_stats_reset(bh_hess* H);
-/* Tuning knobs (kernel geometry, CG launch-ahead depth); unknown keys return BH_ERR_INVALID_ARG. */
+/* Tuning knobs; unknown keys return BH_ERR_INVALID_ARG.  Defaults in brackets.
+ *   "proj_form"      [1] 1 = reduced mA x mA projection (factor built on the device), 0 = the reference's augmented form
+ *                        (needs the caller's factor in bh_proj_set_active)
+ *   "pcg_batch"      [0] CG iterations enqueued per launch-ahead batch; 0 = by problem size (1 when an H*p streams >= 100 us)
+ *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
+ *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
+ *   "chol_downdate"  [1] bh_cauchy_step: rank-one downdate of the factor per breakpoint (0: downdate the Gram matrix, refactor)
+ *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)
+ *   "gram_mfma"      [1] A_free A_free' on fp64 MFMA when mA > 96 (2: always, 0: never)
+ *   "rs_variant"     [0] A/B geometries of the row-streaming kernel for 2048 < n <= 4096 (tools/kernel_ab.py)
+ *   "blocks_per_cu"  [0] workgroups per CU of the row-streaming kernels (0: per-geometry default)
+ *   "pingpong"       [0] alternate the sweep direction of J between consecutive H*p
+ *   "profile"        [flags of bh_init] 1 = hipEvents around every 8th H*p launch (bh_stats: hmul_ms / hmul_timed) */
 int32_t bh_set_option(const char* key, int64_t value);
 /* Time `reps` back-to-back launches of one kernel class with hipEvents on the launch stream.
  * kind: 0 = fused J'(Jp), 1 = J·v, 2 = J'·u; 3..6 = read-only stream probe over the same image (nothing but 16-byte
