@@ -75,6 +75,32 @@ def test_kernel_timers_and_read_probe(bh):
     assert np.array_equal(H * v, before)
 
 
+def test_caller_supplied_stream(bh):
+    """bh_set_stream: the library enqueues on a stream the caller owns (here a torch stream: the same hipStream_t a host
+    framework would hand over); results are the same bits as on the library's own stream, and NULL switches back."""
+    import torch
+    rng = np.random.default_rng(9)
+    J = rng.standard_normal((900, 260)) / 30.0
+    H = bh.AlHessian(J, None, 1.0)
+    Z = np.zeros((0, 260))
+    cons = bh.MixedConstraints(Z)
+    g = rng.standard_normal(260)
+    big = np.full(260, 10.0)
+    w0, st0, info0 = bh.projected_cg(g, H, -big, big, cons, 1e-3, full_output=True)
+    hv0 = H * g
+    lib = bh._lib.lib()
+    stream = torch.cuda.Stream()
+    bh._lib.check(lib.bh_set_stream(bh._lib.C.c_void_p(stream.cuda_stream)), "bh_set_stream")
+    try:
+        w1, st1, info1 = bh.projected_cg(g, H, -big, big, cons, 1e-3, full_output=True)
+        hv1 = H * g
+    finally:
+        bh._lib.check(lib.bh_set_stream(None), "bh_set_stream")
+    assert int(st1) == int(st0) and info1["iters"] == info0["iters"] and info0["iters"] > 8
+    assert np.array_equal(w1, w0) and np.array_equal(hv1, hv0)
+    assert np.array_equal(H * g, hv0)
+
+
 def test_linearity_and_symmetry_at_full_size(bh):
     """Size-independent properties at BASELINE config 3 (d=65536, n=4096; J generated in HBM):
     H(av+bw) = aHv + bHw, v'Hw = w'Hv, v'Hv = vthv(H,v) = ||Jv||^2, and J rows check against the host generator."""
