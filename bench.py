@@ -145,6 +145,9 @@ def main():
     rehearsal = os.environ.get("BH_BENCH_REHEARSAL", "0") not in ("", "0")
     if rehearsal:
         local_rank = 0
+    else:
+        # a launcher that pins one visible device per rank (HIP_VISIBLE_DEVICES) leaves every rank with ordinal 0
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
