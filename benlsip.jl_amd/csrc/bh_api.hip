@@ -68,6 +68,10 @@ struct Ctx {
     CgWorkspace cg;
     double* scratch_dev = nullptr;   // small device scratch (selftest, f2b)
     int live_hess = 0;               // bh_hess handles alive (a handle bakes in this rank's share of C: see bh_comm_init)
+    // dynamic-LDS ceilings already raised on this device (hipFuncSetAttribute); reset by bh_shutdown
+    bool vlds_attr_set = false;      // row_stream_kernel<512,16,1,FUSED,...,VL>
+    bool trsm_lds_granted = false;   // chol_trsm_kernel
+    size_t trsv_lds_granted = 0;     // trsv_pair_kernel
 };
 
 Ctx g_ctx;
@@ -174,11 +178,10 @@ template <int T, int CPT, int R>
 void launch_rs_mode_vlds(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
     if (mode != MODE_FUSED) { launch_rs_mode<T, CPT, R>(mode, a, grid, s); return; }
     constexpr size_t lds = (size_t)T * CPT * sizeof(double2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!g_ctx.vlds_attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        g_ctx.vlds_attr_set = true;
     }
     hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 1>), dim3(grid), dim3(T), lds, s, a);
 }
@@ -608,11 +611,10 @@ int32_t launch_chol(bh_proj* P, const CgState* gate) {
         return BH_OK;
     }
     double* dinv = P->Lr + (int64_t)mA * mA;      // scratch for the current panel's reciprocal diagonal (mA extra doubles)
-    static bool trsm_lds_granted = false;          // 97 KiB of dynamic LDS: above what a kernel may use without asking
-    if (!trsm_lds_granted) {
+    if (!g_ctx.trsm_lds_granted) {                 // 97 KiB of dynamic LDS: above what a kernel may use without asking
         BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_trsm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)kTrsmLdsBytes));
-        trsm_lds_granted = true;
+        g_ctx.trsm_lds_granted = true;
     }
     hipLaunchKernelGGL(copy_lower_kernel, dim3(std::min(1024, (mA * mA + 255) / 256)), dim3(256), 0, s, (const double*)P->M, P->Lr, mA,
                        P->info, gate);
@@ -688,10 +690,9 @@ int trsv_split_for(int m) {
 }
 // The dynamic-LDS ceiling of the kernel is a property of the function, shared by every handle: only ever raise it.
 int32_t ensure_trsv_lds(size_t lds) {
-    static size_t granted = 0;
-    if (lds <= granted) return BH_OK;
+    if (lds <= g_ctx.trsv_lds_granted) return BH_OK;
     BH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&trsv_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    granted = lds;
+    g_ctx.trsv_lds_granted = lds;
     return BH_OK;
 }
 size_t trsv_lds_bytes(int m) {
@@ -790,6 +791,8 @@ int32_t bh_shutdown(void) {
     dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
     g_ctx.own_stream = nullptr; g_ctx.stream = nullptr;
+    if (g_pin.base) { (void)hipHostFree(g_pin.base); g_pin = PinArena(); }
+    g_ctx.vlds_attr_set = false; g_ctx.trsm_lds_granted = false; g_ctx.trsv_lds_granted = 0;
     g_ctx.init = false; g_ctx.rank = 0; g_ctx.nranks = 1;
     return BH_OK;
 }

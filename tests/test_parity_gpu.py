@@ -546,6 +546,50 @@ assert bh._lib.lib().bh_comm_destroy() == 0
     assert tok[0] == "OK" and int(tok[1]) >= 3 + int(tok[2])      # hmul + jtv + vthv + one per H*p of the CG run
 
 
+def test_shutdown_and_reinit_in_one_process():
+    """bh_shutdown releases the library's device state (workspace, pinned arena, LDS ceilings); a second bh_init in the same
+    process starts clean and reproduces the first life's results bit for bit (wide J, a blocked factor and a CG run, so that
+    every lazily raised per-kernel limit is raised again)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import benlsip_jl_amd as bh
+rng = np.random.default_rng(3)
+J = rng.standard_normal((40, 9000)) / 7.0
+A = rng.standard_normal((130, 400))
+Js = rng.standard_normal((900, 400)) / 30.0
+g = rng.standard_normal(400)
+def life():
+    bh.init(0)
+    H = bh.AlHessian(J, None, 1.0)
+    hv = H * np.ones(9000)
+    Hs = bh.AlHessian(Js, None, 1.0)
+    cons = bh.MixedConstraints(A, None, None)
+    big = np.full(400, 5.0)
+    w, st, info = bh.projected_cg(g, Hs, -big, big, cons, 1e-2, full_output=True)
+    pv = bh.projection(cons, g)
+    H.close(); Hs.close(); cons.close()
+    assert bh._lib.lib().bh_shutdown() == 0
+    return hv, w, int(st), info["iters"], pv
+a = life()
+try:
+    bh.AlHessian(Js, None, 1.0)
+    raise SystemExit("a call after bh_shutdown must fail")
+except bh.BenlsipHipError as e:
+    assert e.code == bh._lib.BH_ERR_NOT_INIT
+b = life()
+assert all(np.array_equal(x, y) for x, y in zip(a, b))
+print("OK", a[2], a[3])
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1].startswith("OK")
+
+
 def test_workspace_reuse_across_sizes_and_odd_n(bh):
     """The CG workspace is shared by all calls: a larger problem must not leak into the padding of a later smaller / odd-n
     one (box and general path)."""
