@@ -794,7 +794,8 @@ def test_gram_on_matrix_cores_matches_valu_path(bh, mA, n, nfix):
 
 def test_pcg_config3_full_size_against_oracle(bh):
     """BASELINE config 3 itself (d = 65536, n = 4096, box, p = 512; the bench.py workload): the device-generated J against the
-    host generator (full 2 GiB image through J v and J' u) and projected_cg against the oracle at full size."""
+    host generator (full 2 GiB image through J v and J' u) and projected_cg against the oracle at full size; then config 5
+    (the same J with 64 linear equalities) against the oracle, both projection forms."""
     d, n = 65536, 4096
     J = np.empty((d, n), order="F")
     for r0 in range(0, d, 8192):                      # host generator in row slabs (bounds the temporaries)
@@ -818,6 +819,24 @@ def test_pcg_config3_full_size_against_oracle(bh):
         assert int(status) == int(s_ref) and info["iters"] == it_ref and info["n_hmul"] == tr.n_hmul
         assert relnorm(w, w_ref) <= 1e-9, relnorm(w, w_ref)
         np.testing.assert_allclose(info["trace"], np.array(tr.rows), rtol=1e-9)
+    # BASELINE config 5 at its full size on the same J: 64 linear equalities (A = u(4, .)) + the 512 active bounds, both
+    # projection forms (reduced form on the device; the reference's augmented 576 x 576 factor from the oracle)
+    mA = 64
+    A5 = R.splitmix_uniform(4, np.arange(mA * n)).reshape((mA, n), order="F")
+    cons5_o = R.make_mixed_constraints(A5, R.chol_lower(A5 @ A5.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons5_o, 0.01)
+    lib = bh._lib.lib()
+    for form in (1, 0):
+        lib.bh_set_option(b"proj_form", form)
+        cons5 = bh.MixedConstraints(A5, cons5_o.chol_L, inst.fixvars, l=inst.x_l, u=inst.x_u)
+        w, status, info = bh.projected_cg(g, H, w_l, w_u, cons5, 0.01, full_output=True)
+        lib.bh_set_option(b"proj_form", 1)
+        assert int(status) == int(s_ref) and info["iters"] == it_ref, (form, int(status), int(s_ref), info["iters"], it_ref)
+        assert relnorm(w, w_ref) <= 1e-8, (form, relnorm(w, w_ref))
+        assert np.linalg.norm(A5 @ w) <= 1e-10 * np.linalg.norm(A5) * np.linalg.norm(w)
+        # fixed components: exact zeros in the reduced form; rounding-level in the augmented form, as in the reference
+        assert np.max(np.abs(w[inst.fixvars])) <= (0.0 if form == 1 else 1e-12 * np.linalg.norm(w))
+        cons5.close()
     H.close()
 
 
