@@ -25,6 +25,15 @@ int bo_num_threads(void) {
 #endif
 }
 
+/* Cap the OpenMP team (medium-sized test problems run an order of magnitude slower on a 128-thread team than on 8). */
+void bo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* t = J v  (dgemv 'N'), J d x n column-major.  Row blocks per thread, columns streamed with unit stride. */
 static void gemv_n(const double* J, long d, long n, long ld, const double* v, double* t) {
 #pragma omp parallel if (d * n > 2000000L)   /* small products: a parallel region costs more than the product */

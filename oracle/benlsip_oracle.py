@@ -20,6 +20,8 @@ def load(build=True):
     lib = C.CDLL(path)
     vp, L, D = C.c_void_p, C.c_long, C.c_double
     lib.bo_num_threads.restype = C.c_int
+    lib.bo_set_num_threads.argtypes = [C.c_int]
+    lib.bo_set_num_threads.restype = None
     lib.bo_hmul.argtypes = [vp, L, L, L, vp, L, L, D, vp, vp, vp]
     lib.bo_hmul.restype = None
     lib.bo_vthv.argtypes = [vp, L, L, L, vp, L, L, D, vp, vp]
@@ -45,6 +47,13 @@ def _p(a):
 
 def num_threads():
     return load().bo_num_threads()
+
+
+def set_num_threads(n):
+    """Cap the OpenMP team size of the following calls; returns the previous maximum."""
+    prev = load().bo_num_threads()
+    load().bo_set_num_threads(int(n))
+    return prev
 
 
 def hmul(J, Cm, mu, v):

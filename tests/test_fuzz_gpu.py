@@ -137,3 +137,58 @@ def test_fuzz_cauchy_step_and_minor_iterate(bh, seed):
         H.close()
     lib.bh_set_option(b"chol_downdate", 1)
     assert not mism, "\n".join(str(m) for m in mism)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_medium_shapes(bh, seed):
+    """Medium shapes that cross the kernel-geometry classes (n from 100 to 5000: every row-stream configuration below the
+    wide ones), factor orders on both sides of 64 (one-wave vs blocked Cholesky / triangular solves, 4 vs 16 row groups in
+    the transposed multiply) and both projection forms: projection and projected_cg against the oracles."""
+    rng = np.random.default_rng(9000 + seed)
+    lib = bh._lib.lib()
+    mism = []
+    try:        # the GPU box's 128 BLAS threads make these medium-sized oracle calls an order of magnitude slower than 8 do
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=8)
+    except Exception:
+        limiter = None
+    omp_prev = BO.set_num_threads(8)
+    for case in range(10):
+        n = int(rng.choice([100, 130, 257, 512, 700, 1025, 1500, 2049, 3000, 4100, 5000]))
+        d = int(rng.integers(n // 2, 2 * n))
+        mA = int(rng.choice([0, 1, 7, 63, 64, 65, 100, 129, 200])) if n >= 512 else int(rng.choice([0, 3, 40]))
+        nfix = int(rng.integers(0, (n - mA) // 2))
+        form = int(rng.integers(0, 2)) if mA + nfix <= 1500 else 1         # keep the oracle's augmented factor affordable
+        lib.bh_set_option(b"proj_form", form)
+        J = rng.standard_normal((d, n)) / np.sqrt(d)
+        A = rng.standard_normal((mA, n))
+        fix = np.zeros(n, dtype=bool)
+        if nfix:
+            fix[rng.choice(n, nfix, replace=False)] = True
+        cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix if nfix else None, l=-np.ones(n), u=np.ones(n))
+        H, Ho = bh.AlHessian(J, None, 1.0), R.AlHessian(J, np.zeros((0, n)), 1.0)
+        cons = bh.MixedConstraints(A, cons_o.chol_L, fix)
+        r = rng.standard_normal(n)
+        v_ref = R.projection(cons_o, r)
+        v = bh.projection(cons, r)
+        if np.linalg.norm(v - v_ref) > 1e-9 * np.linalg.norm(r):
+            mism.append(("projection", case, n, d, mA, nfix, form, np.linalg.norm(v - v_ref) / np.linalg.norm(r)))
+        x_minor = np.clip(0.3 * rng.standard_normal(n), -0.9, 0.9)
+        x_minor[fix] = 1.0
+        g = rng.standard_normal(n)
+        w_l, w_u = R.build_step_bounds(x_minor, cons_o, 0.5 * np.linalg.norm(g))
+        w0, s0, it0 = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+        w, st, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
+        ok = int(st) == int(s0) and info["iters"] == it0 and (not np.all(np.isfinite(w0)) or relnorm(w, w0) <= 1e-6)
+        if not ok:
+            # rounding or bug?  the C restatement decides (reduced instances only need its chol of the augmented matrix)
+            w1, s1, it1, _, _ = BO.projected_cg(g, J, np.zeros((0, n)), 1.0, w_l, w_u, A, fix, cons_o.chol_L, 0.1)
+            if (int(s1), it1) == (int(s0), it0) and (not np.all(np.isfinite(w0)) or relnorm(w1, w0) <= 1e-2 * max(relnorm(w, w0), 1e-300)):
+                mism.append(("pcg", case, n, d, mA, nfix, form, int(s0), int(st), it0, info["iters"], relnorm(w, w0)))
+        H.close()
+        cons.close()
+    lib.bh_set_option(b"proj_form", 1)
+    if limiter is not None:
+        limiter.restore_original_limits()
+    BO.set_num_threads(omp_prev)
+    assert not mism, "\n".join(str(m) for m in mism)
