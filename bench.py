@@ -27,6 +27,28 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_M
 HBM_COPY_CEILING_GBS = 6290.0   # the same guide's measured float4-copy figure (read + write streams; this path is read-only)
 
 
+def cpu_share():
+    """Host CPUs this process may actually use: the cgroup quota when there is one (the GPU boxes expose 128 hardware
+    threads but a 16-CPU share; BLAS teams larger than the share get throttled), else the affinity mask / CPU count."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(round(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, int(round(q / p)))
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS):
     syn = bh.synthetic
     d_total = d_per_gpu * world
@@ -92,7 +114,8 @@ def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, d_sample=
     # the C/OpenMP port at several team sizes (a 128-thread team is not the fastest for a memory-bound dgemv), best kept
     omp_max = BO.num_threads()
     t_c, reps_c, omp_best, by_team = None, 0, omp_max, {}
-    for team in sorted({t for t in (8, 16, 32, 64, omp_max) if t <= omp_max}):
+    share = cpu_share()
+    for team in sorted({t for t in (8, 16, 32, 64, share, omp_max) if t <= omp_max}):
         BO.set_num_threads(team)
         t_k, reps_k = timed(lambda: BO.projected_cg(g, J, Z, 10.0, w_l, w_u, A, inst.fixvars, cons.chol_L, kappa2)[3], 2.5)
         by_team[team] = 1e3 * t_k * (d_full / d_sample)
@@ -126,7 +149,7 @@ def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, d_sample=
                   % (d_sample, d_full, n, d_full // d_sample, which, reps_c if which == "C/OpenMP" else reps_np, d_full // d_sample, n_hmul_gpu),
         "ms_per_hmul_full_size": {"c_openmp": 1e3 * t_c * scale, "numpy_openblas": 1e3 * t_np * scale},
         "threads": {"c_openmp": int(omp_best), "numpy_openblas": int(np_threads)},
-        "c_openmp_ms_per_hmul_by_team": by_team,
+        "c_openmp_ms_per_hmul_by_team": by_team, "cpu_share": share, "hardware_threads": os.cpu_count(),
         "host_gbs": 2 * 8.0 * d_sample * n / best / 1e9,
     }
 
@@ -144,6 +167,13 @@ def main():
                     help="skip the ill-conditioned extra run (its over-launched no-op kernels would pull down rocprofv3's per-kernel average)")
     args = ap.parse_args()
 
+    # keep idle BLAS worker teams within the CPU share: a 128-thread team spinning on a 16-CPU quota gets the whole
+    # process throttled for tens of milliseconds at a time — also while it only drives the GPU
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=cpu_share())
+    except Exception:
+        pass
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

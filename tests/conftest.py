@@ -9,8 +9,33 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+def _cpu_share():
+    """CPUs this process may use: the cgroup quota when there is one (the GPU box shows 128 hardware threads but grants a
+    16-CPU share), else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return max(1, int(round(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracles (NumPy/OpenBLAS, C/OpenMP) must not run teams larger than the CPU share: they get throttled, which makes
+    # the suite several times slower and stalls the GPU-driving thread of the same process as well.
+    share = _cpu_share()
+    os.environ.setdefault("OMP_NUM_THREADS", str(share))            # inherited by the tests' child processes
+    os.environ.setdefault("OPENBLAS_NUM_THREADS", str(share))
+    try:
+        from threadpoolctl import threadpool_limits
+        config._bh_blas_cap = threadpool_limits(limits=share)
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
