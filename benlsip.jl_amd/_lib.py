@@ -23,7 +23,7 @@ EXPORTS = [
     "bh_hmul", "bh_vthv", "bh_jv", "bh_jtv", "bh_hmul_dev", "bh_jv_dev", "bh_jtv_dev",
     "bh_proj_create", "bh_proj_set_active", "bh_proj_destroy", "bh_proj_shape", "bh_project", "bh_project_dev",
     "bh_left_mul", "bh_left_mul_tr",
-    "bh_pcg", "bh_pcg_dev", "bh_factor_to_boundary", "bh_minor_iterate", "bh_linesearch", "bh_grad", "bh_hmul_add", "bh_cauchy_step",
+    "bh_pcg", "bh_pcg_dev", "bh_pcg_tie_info", "bh_resid_sqnorm", "bh_factor_to_boundary", "bh_minor_iterate", "bh_linesearch", "bh_grad", "bh_hmul_add", "bh_cauchy_step",
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_stats", "bh_stats_reset",
     "bh_set_option", "bh_time_kernel", "bh_selftest",
 ]
@@ -82,6 +82,8 @@ _PROTOS = {
                 C.POINTER(_i32)], _i32),
     "bh_pcg_dev": ([_vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _vp, C.POINTER(_i32), C.POINTER(_i32), _vp, _i64,
                     C.POINTER(_i32)], _i32),
+    "bh_pcg_tie_info": ([_vp, C.POINTER(_i32), C.POINTER(_i32), _dp, C.POINTER(_i32), C.POINTER(_i32)], _i32),
+    "bh_resid_sqnorm": ([_vp, _i64, _dp], _i32),
     "bh_factor_to_boundary": ([_vp, _vp, _vp, _vp, _i64, _f64, _dp], _i32),
     "bh_minor_iterate": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, C.POINTER(_i32), C.POINTER(_i32),
                          C.POINTER(_i32), _dp], _i32),

@@ -4,9 +4,14 @@
 #include "bh_kernels.hip.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>   // types only: librccl is dlopen'ed in bh_comm_init (never needed on one GPU)
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -37,6 +42,28 @@ struct CgWorkspace {
     int64_t trace_cap = 0;
 };
 
+// Host side of the peer-buffer exchange: this rank's inbox, the peers' inboxes mapped through hipIpc, and the POSIX
+// shared-memory page the ranks of one node meet on to swap handles (named after the communicator's unique id).
+struct PeerShm {
+    std::atomic<int> arrive;
+    std::atomic<int> generation;
+    int failed;
+    hipIpcMemHandle_t handle[kMaxPeers];
+};
+struct PeerComm {
+    bool active = false;
+    void* inbox = nullptr;                   // slots | flags | seq, arrive   (one allocation: one IPC handle)
+    size_t inbox_bytes = 0;
+    void* peer_base[kMaxPeers] = {};         // mapped inboxes (own rank: inbox)
+    volatile unsigned long long* h_err = nullptr;   // host-mapped error word
+    PeerShm* shm = nullptr;
+    PeerArgs args{};
+};
+constexpr int64_t kPeerCap = 1 << 16;                                   // doubles per slot (512 KiB): larger vectors go in pieces
+constexpr int kPeerBlkCap = (int)(kPeerCap / (2 * kPeerBlockChunks));   // 2048 flags per (parity, rank)
+constexpr size_t kPeerSlotBytes = (size_t)2 * kMaxPeers * kPeerCap * sizeof(double);
+constexpr size_t kPeerFlagBytes = (size_t)2 * kMaxPeers * kPeerBlkCap * sizeof(unsigned long long);
+
 struct Ctx {
     bool init = false;
     int device = -1;
@@ -65,8 +92,13 @@ struct Ctx {
     ncclResult_t (*p_ncclCommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*p_ncclAllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*p_ncclGetErrorString)(ncclResult_t) = nullptr;
+    // one-shot all-reduce over peer-mapped inboxes (bh_comm.hip.h); comm_path selects it (1) or RCCL (0) when both exist
+    PeerComm peer;
+    int comm_path = 0;
     CgWorkspace cg;
     double* scratch_dev = nullptr;   // small device scratch (selftest, f2b)
+    double* rbuf = nullptr;          // residual staging of bh_resid_sqnorm (grown on demand)
+    int64_t rbuf_cap = 0;
     int live_hess = 0;               // bh_hess handles alive (a handle bakes in this rank's share of C: see bh_comm_init)
     // dynamic-LDS ceilings already raised on this device (hipFuncSetAttribute); reset by bh_shutdown
     bool vlds_attr_set = false;      // row_stream_kernel<512,16,1,FUSED,...,VL>
@@ -76,11 +108,17 @@ struct Ctx {
 
 Ctx g_ctx;
 
-void pin_arena_abandon();   // drops results parked for a call that is about to fail
+void pin_arena_abandon(bool drained);   // drops results parked for a call that is about to fail
+bool pin_arena_busy();
 
-int32_t fail(int32_t code, const std::string& what) {
+// drain: DMAs queued by stage_vec / fetch_vec may still be reading or writing the pinned arena; wait for them before the
+// arena is handed to the next call.  A caller that is failing BECAUSE the stream makes no progress passes drain = false
+// (the arena is then retired instead of reused).
+int32_t fail(int32_t code, const std::string& what, bool drain = true) {
     g_ctx.detail = what;
-    pin_arena_abandon();
+    bool drained = true;
+    if (pin_arena_busy()) drained = drain && g_ctx.stream != nullptr && hipStreamSynchronize(g_ctx.stream) == hipSuccess;
+    pin_arena_abandon(drained);
     return code;
 }
 
@@ -140,6 +178,7 @@ const RsConfig kRsConfigs[] = {
     {512, 16, 1, 1},   // 14: nchunks <= 8192 (n <= 16384): one row per step; the fused mode parks v in LDS (VL)
 };
 constexpr int64_t kMaxChunks = 8192;
+constexpr int64_t kMaxBlocksPerCu = 8;   // partial-slab capacity per handle: n_cu * kMaxBlocksPerCu workgroups (alloc_hess_common)
 
 int pick_config(int nchunks) {
     if (nchunks <= 64) return 0;
@@ -210,7 +249,7 @@ int grid_for(int cfg, int64_t nrows) {
     const RsConfig& c = kRsConfigs[cfg];
     const int64_t ngroups = (nrows + c.R - 1) / c.R;
     const int64_t bpc = g_ctx.opt_blocks_per_cu > 0 ? g_ctx.opt_blocks_per_cu : c.blocks_per_cu;
-    int64_t g = (int64_t)g_ctx.n_cu * bpc;
+    int64_t g = (int64_t)g_ctx.n_cu * std::min<int64_t>(bpc, kMaxBlocksPerCu);   // the slab buffers hold n_cu * kMaxBlocksPerCu rows
     g = std::min<int64_t>(g, std::max<int64_t>(ngroups, 1));
     return (int)g;
 }
@@ -225,6 +264,7 @@ constexpr int kEvStride = 8;
 // ------------------------------------------------------------------------------------------
 struct bh_hess {
     int64_t d = 0, n = 0, q = 0, q_eff = 0, ld = 0;
+    int64_t d_total = 0;           // rows of J over all ranks (= d on one rank): sizes the launch-ahead batch identically everywhere
     int nchunks = 0;
     double mu = 0.0;
     double* Jd = nullptr;          // (d + q) x ld row-major
@@ -237,6 +277,9 @@ struct bh_hess {
     double* scalar = nullptr;      // 2
     int g_cap = 0;
     int last_n_hmul = 0;           // H*p count of the previous bh_pcg on this handle (launch schedule hint)
+    // tie log of the previous projected_cg on this handle (bh_pcg_tie_info)
+    int tie_flags = 0, tie_first = 0, margin_kind = 0, margin_at = 0;
+    double min_margin = 0.0;
     bh_stats_t stats{};
     std::vector<hipEvent_t> ev;    // 2*kEvCap, created lazily
     std::vector<int> ev_pending;   // launch index (within the running bh_pcg) of each recorded pair
@@ -298,6 +341,7 @@ int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
 }
 
 struct MirrorWord { int done, status, iter, n_hmul; };
+int32_t check_peer_error();
 
 // Spin on the host-mapped progress word until this call's tag shows `done` or at least `target` H*p products.
 int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
@@ -314,6 +358,7 @@ int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
         }
         __builtin_ia32_pause();
         if ((++spins & 0xffff) == 0) {
+            if (g_ctx.peer.active && *g_ctx.peer.h_err != 0ull) return check_peer_error();
             hipError_t q = hipStreamQuery(g_ctx.stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(BH_ERR_HIP, std::string("CG loop: ") + hipGetErrorString(q));
             if (q == hipSuccess) {
@@ -324,16 +369,56 @@ int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
                 continue;
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
-                return fail(BH_ERR_HIP, "CG loop: no progress for 120 s");
+                return fail(BH_ERR_HIP, "CG loop: no progress for 120 s", /*drain=*/false);
         }
     }
 }
 
-int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H) {
-    if (g_ctx.comm == nullptr) return BH_OK;
-    BH_NCCL(g_ctx.p_ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_ctx.comm, g_ctx.stream));
+bool comm_active() { return g_ctx.comm != nullptr || g_ctx.peer.active; }
+// the peer-buffer exchange is used when it is the only communicator, or when option "comm_path" = 1 selects it
+bool use_peer_path() { return g_ctx.peer.active && (g_ctx.comm_path == 1 || g_ctx.comm == nullptr); }
+
+// buf[0, count) <- sum over ranks, in place, on the library stream.  `buf` must be addressable in whole 16-byte chunks
+// (every caller passes a padded workspace vector).  state: the device-side gate of a CG / Cauchy loop — honoured by the
+// peer-buffer path; an RCCL call cannot be gated from the device, so over-launched iterations still pay for it there.
+int32_t allreduce_inplace(double* buf, int64_t count, bh_hess* H, const CgState* state = nullptr) {
+    if (!comm_active() || count <= 0) return BH_OK;
+    if (use_peer_path()) {
+        for (int64_t off = 0; off < count; off += kPeerCap) {
+            const int nch = (int)((std::min(kPeerCap, count - off) + 1) / 2);
+            hipLaunchKernelGGL(reduce_exchange_kernel, dim3((nch + kPeerBlockChunks - 1) / kPeerBlockChunks), dim3(256), 0, g_ctx.stream,
+                               (const double*)nullptr, (int64_t)0, nch, 0, buf + off, state, g_ctx.peer.args);
+        }
+        BH_HIP(hipGetLastError());
+    } else {
+        BH_NCCL(g_ctx.p_ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, g_ctx.comm, g_ctx.stream));
+    }
     if (H) H->stats.n_allreduce += 1;
     return BH_OK;
+}
+
+int32_t check_peer_error() {
+    if (g_ctx.peer.active && g_ctx.peer.h_err != nullptr && *g_ctx.peer.h_err != 0ull)
+        return fail(BH_ERR_RCCL, "peer-buffer all-reduce: a rank did not arrive within the timeout (exchange #" +
+                                     std::to_string(*g_ctx.peer.h_err) + "); results are invalid", /*drain=*/false);
+    return BH_OK;
+}
+
+// z_out (ld doubles) = sum over ranks of the fixed-order sum of the `grid` slab rows a row-stream launch left in
+// H->partials.  One launch either way on one rank; with the peer-buffer communicator the exchange is fused into the slab
+// reduction (reduce_exchange_kernel), with RCCL it is a separate collective behind reduce_partials_kernel.
+int32_t reduce_slabs(bh_hess* H, int grid, double* z_out, const CgState* state) {
+    const int nblk = (H->nchunks + kPeerBlockChunks - 1) / kPeerBlockChunks;
+    if (use_peer_path() && nblk <= kPeerBlkCap) {
+        hipLaunchKernelGGL(reduce_exchange_kernel, dim3(nblk), dim3(256), 0, g_ctx.stream, (const double*)H->partials, H->ld, H->nchunks,
+                           grid, z_out, state, g_ctx.peer.args);
+        BH_HIP(hipGetLastError());
+        H->stats.n_allreduce += 1;
+        return BH_OK;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nblk), dim3(256), 0, g_ctx.stream, H->partials, H->ld, H->nchunks, grid, z_out, state);
+    BH_HIP(hipGetLastError());
+    return allreduce_inplace(z_out, H->n, H, state);
 }
 
 // Column panels: a row wider than the register-resident kernels can hold (ld/2 > kMaxChunks) is swept in panels of
@@ -375,10 +460,8 @@ int32_t launch_jtv_panels(bh_hess* H, const double* u, double* z_out, int64_t nr
         a.u = u; a.weighted_u = weighted ? 1 : 0;
         launch_row_stream(kPanelCfg, MODE_JTV, a, grid, g_ctx.stream);
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
-                       H->partials, H->ld, H->nchunks, grid, z_out, state);
     BH_HIP(hipGetLastError());
-    return BH_OK;
+    return reduce_slabs(H, grid, z_out, state);       // includes the all-reduce over ranks
 }
 
 // z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
@@ -388,7 +471,6 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
     if (multi_panel(H)) {
         BH_TRY(launch_jv_panels(H, v_pad, H->tbuf, nrows, state));
         BH_TRY(launch_jtv_panels(H, H->tbuf, z_out, nrows, true, state));
-        BH_TRY(allreduce_inplace(z_out, H->n, H));
         return BH_OK;
     }
     const int cfg = pick_config(H->nchunks);
@@ -414,11 +496,7 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
     }
     launch_row_stream(cfg, MODE_FUSED, a, grid, g_ctx.stream);
     if (timed) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], g_ctx.stream));
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
-                       H->partials, H->ld, H->nchunks, grid, z_out, state);
-    BH_HIP(hipGetLastError());
-    BH_TRY(allreduce_inplace(z_out, H->n, H));
-    return BH_OK;
+    return reduce_slabs(H, grid, z_out, state);
 }
 
 int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_rows, double* sq_out_scalar) {
@@ -448,7 +526,6 @@ int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out, bool with_c_r
     const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
     if (multi_panel(H)) {
         BH_TRY(launch_jtv_panels(H, u_dev, z_out, nrows, false, nullptr));
-        BH_TRY(allreduce_inplace(z_out, H->n, H));
         return BH_OK;
     }
     const int cfg = pick_config(H->nchunks);
@@ -456,11 +533,7 @@ int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out, bool with_c_r
     RowStreamArgs a = rs_args(H, nrows, nullptr);
     a.u = u_dev; a.partials = H->partials;
     launch_row_stream(cfg, MODE_JTV, a, grid, g_ctx.stream);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((H->nchunks + 15) / 16), dim3(256), 0, g_ctx.stream,
-                       H->partials, H->ld, H->nchunks, grid, z_out, (const CgState*)nullptr);
-    BH_HIP(hipGetLastError());
-    BH_TRY(allreduce_inplace(z_out, H->n, H));
-    return BH_OK;
+    return reduce_slabs(H, grid, z_out, nullptr);
 }
 
 int32_t alloc_hess_common(bh_hess* H) {
@@ -476,12 +549,29 @@ int32_t alloc_hess_common(bh_hess* H) {
     BH_HIP(hipMemsetAsync(H->vpad, 0, H->ld * sizeof(double), g_ctx.stream));
     BH_HIP(hipMemsetAsync(H->zpad, 0, H->ld * sizeof(double), g_ctx.stream));
     // partial slabs: enough for the largest grid any variant may use
-    int64_t gmax = (int64_t)g_ctx.n_cu * 8;
+    int64_t gmax = (int64_t)g_ctx.n_cu * kMaxBlocksPerCu;
     H->g_cap = (int)gmax;
     BH_TRY(dev_alloc(&H->partials, gmax * H->ld));
     BH_TRY(dev_alloc(&H->sq_partials, gmax));
     BH_TRY(dev_alloc(&H->scalar, 2));
     H->stats.bytes_per_hmul = (multi_panel(H) ? 16.0 : 8.0) * (double)(H->d + H->q_eff) * (double)H->n + 16.0 * (double)H->n;
+    return BH_OK;
+}
+
+// Last step of every bh_hess constructor.  With a communicator the ranks' row counts are summed once: everything that
+// shapes the launch schedule (launch_batch_size) must be computed from data that is identical on all ranks, or ranks would
+// enqueue different numbers of iterations — and of collectives (q_eff and the +-1 row of row_shard differ between ranks).
+int32_t finish_hess_create(bh_hess* H) {
+    H->d_total = H->d;
+    if (comm_active()) {
+        double v[2] = {(double)H->d, 0.0};
+        BH_HIP(hipMemcpyAsync(H->scalar, v, sizeof(v), hipMemcpyHostToDevice, g_ctx.stream));
+        BH_TRY(allreduce_inplace(H->scalar, 1, nullptr));
+        BH_HIP(hipMemcpyAsync(v, H->scalar, sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
+        BH_HIP(hipStreamSynchronize(g_ctx.stream));
+        BH_TRY(check_peer_error());
+        H->d_total = (int64_t)std::llround(v[0]);
+    }
     return BH_OK;
 }
 
@@ -526,7 +616,14 @@ struct PinArena {
     std::vector<PendingOut> outs;
 };
 PinArena g_pin;
-void pin_arena_abandon() { g_pin.outs.clear(); g_pin.used = 0; }
+bool pin_arena_busy() { return g_pin.used > 0; }
+void pin_arena_abandon(bool drained) {
+    g_pin.outs.clear();
+    g_pin.used = 0;
+    // transfers may still be in flight (the stream could not be drained): retire this arena — it is leaked on purpose,
+    // a later pin_alloc maps a fresh one — rather than let the next call's vectors share memory with a stale DMA
+    if (!drained) { g_pin.base = nullptr; g_pin.cap = 0; }
+}
 constexpr size_t kPinArenaBytes = 32u << 20;
 constexpr int64_t kPinMaxVec = 1 << 20;     // doubles; larger transfers go directly (bandwidth-, not latency-bound)
 
@@ -581,7 +678,7 @@ int32_t sync_flush() {
     g_pin.outs.clear();
     g_pin.used = 0;
     if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-    return BH_OK;
+    return check_peer_error();
 }
 
 // ---- projection -------------------------------------------------------------------------
@@ -755,6 +852,8 @@ const char* bh_last_error_detail(void) { return g_ctx.detail.c_str(); }
 
 int32_t bh_init(int32_t device, int32_t flags) {
     if (g_ctx.init) {
+        if (device != g_ctx.device)
+            return fail(BH_ERR_INVALID_ARG, "bh_init: already initialised on another device (bh_shutdown first)");
         g_ctx.flags = flags;
         return BH_OK;
     }
@@ -772,7 +871,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     g_ctx.stream = g_ctx.own_stream;
     BH_TRY(dev_alloc(&g_ctx.scratch_dev, 1024));
     if (const char* s = getenv("BH_RS_VARIANT")) g_ctx.opt_variant = atoll(s);
-    if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = atoll(s);
+    if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = std::min<int64_t>(std::max<int64_t>(0, atoll(s)), kMaxBlocksPerCu);
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(0, atoll(s));
     if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_PROJ_FORM")) g_ctx.opt_proj_form = atoll(s) ? 1 : 0;
@@ -780,15 +879,20 @@ int32_t bh_init(int32_t device, int32_t flags) {
     return BH_OK;
 }
 
+static void peer_release(bool with_barrier);
+
 int32_t bh_shutdown(void) {
     if (!g_ctx.init) return BH_OK;
     (void)hipStreamSynchronize(g_ctx.stream);
     if (g_ctx.comm && g_ctx.p_ncclCommDestroy) { g_ctx.p_ncclCommDestroy(g_ctx.comm); g_ctx.comm = nullptr; }
+    if (g_ctx.peer.active) peer_release(true);
+    g_ctx.comm_path = 0;
     CgWorkspace& c = g_ctx.cg;
     dev_free(c.slab); dev_free(c.d_state); dev_free(c.d_trace);
     if (c.h_mirror) (void)hipHostFree(const_cast<unsigned long long*>(c.h_mirror));
     c = CgWorkspace();
     dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
+    dev_free(g_ctx.rbuf); g_ctx.rbuf = nullptr; g_ctx.rbuf_cap = 0;
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
     g_ctx.own_stream = nullptr; g_ctx.stream = nullptr;
     if (g_pin.base) { (void)hipHostFree(g_pin.base); g_pin = PinArena(); }
@@ -823,7 +927,11 @@ int32_t bh_device_info(char* name_out, int64_t name_cap, int32_t* n_cu, char* ar
 int32_t bh_set_option(const char* key, int64_t value) {
     if (!key) return fail(BH_ERR_INVALID_ARG, "NULL key");
     if (!strcmp(key, "rs_variant")) { g_ctx.opt_variant = value; return BH_OK; }
-    if (!strcmp(key, "blocks_per_cu")) { g_ctx.opt_blocks_per_cu = value; return BH_OK; }
+    if (!strcmp(key, "blocks_per_cu")) {
+        if (value < 0 || value > kMaxBlocksPerCu) return fail(BH_ERR_INVALID_ARG, "blocks_per_cu must be 0 (default) .. 8");
+        g_ctx.opt_blocks_per_cu = value;
+        return BH_OK;
+    }
     if (!strcmp(key, "pcg_batch")) { g_ctx.opt_batch = std::max<int64_t>(0, value); return BH_OK; }
     if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
@@ -832,6 +940,14 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "comm_path")) {
+        if (value == 1 && !g_ctx.peer.active) return fail(BH_ERR_PRECONDITION, "comm_path = 1 needs the peer-buffer communicator (BH_COMM=ipc or both)");
+        if (value == 0 && comm_active() && g_ctx.comm == nullptr) return fail(BH_ERR_PRECONDITION, "comm_path = 0 needs an RCCL communicator (BH_COMM=rccl or both)");
+        if (value != 0 && value != 1) return fail(BH_ERR_INVALID_ARG, "comm_path is 0 (RCCL) or 1 (peer buffers)");
+        if (g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);
+        g_ctx.comm_path = (int)value;
+        return BH_OK;
+    }
     if (!strcmp(key, "profile")) { g_ctx.flags = value ? (g_ctx.flags | BH_FLAG_PROFILE) : (g_ctx.flags & ~BH_FLAG_PROFILE); return BH_OK; }
     return fail(BH_ERR_INVALID_ARG, std::string("unknown option ") + key);
 }
@@ -839,10 +955,8 @@ int32_t bh_set_option(const char* key, int64_t value) {
 // ---- multi-GPU -----------------------------------------------------------------------------
 static int32_t load_rccl() {
     if (g_ctx.rccl_lib) return BH_OK;
-    // BH_RCCL_LIB names a specific build (the multi-process test points it at a host-staged stand-in so that two ranks
-    // can share the one GPU of a test box; RCCL itself refuses duplicate devices).  Otherwise by SONAME: glibc hands
-    // back the copy the process has already mapped (e.g. the one libtorch_hip.so brought in), so there is one RCCL
-    // per process.
+    // BH_RCCL_LIB names a specific build.  Otherwise by SONAME: glibc hands back the copy the process has already mapped
+    // (e.g. the one libtorch_hip.so brought in), so there is one RCCL per process.
     const char* names[] = {getenv("BH_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* nm : names) {
         if (!nm || !*nm) continue;
@@ -863,44 +977,178 @@ static int32_t load_rccl() {
     return BH_OK;
 }
 
+// Which communicators bh_comm_init brings up: BH_COMM = "rccl" (default), "ipc" (peer-buffer exchange only: no librccl
+// needed) or "both" (RCCL carries the all-reduces until bh_set_option("comm_path", 1) switches to the peer buffers).
+enum { COMM_RCCL = 1, COMM_IPC = 2 };
+static int comm_mode() {
+    const char* m = getenv("BH_COMM");
+    if (!m || !*m || !strcmp(m, "rccl")) return COMM_RCCL;
+    if (!strcmp(m, "ipc") || !strcmp(m, "peer")) return COMM_IPC;
+    if (!strcmp(m, "both")) return COMM_RCCL | COMM_IPC;
+    return 0;
+}
+
+static bool peer_barrier(PeerShm* shm, int nranks, int timeout_s) {
+    const int gen = shm->generation.load(std::memory_order_acquire);
+    if (shm->arrive.fetch_add(1, std::memory_order_acq_rel) + 1 == nranks) {
+        shm->arrive.store(0, std::memory_order_relaxed);
+        shm->generation.store(gen + 1, std::memory_order_release);
+        return true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (shm->generation.load(std::memory_order_acquire) == gen) {
+        sched_yield();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s)) return false;
+    }
+    return true;
+}
+
+static void peer_release(bool with_barrier) {
+    PeerComm& pc = g_ctx.peer;
+    if (pc.shm && with_barrier) (void)peer_barrier(pc.shm, g_ctx.nranks, 20);   // nobody unmaps while a peer may still push
+    for (int p = 0; p < kMaxPeers; ++p)
+        if (pc.peer_base[p] && pc.peer_base[p] != pc.inbox) (void)hipIpcCloseMemHandle(pc.peer_base[p]);
+    if (pc.inbox) (void)hipFree(pc.inbox);
+    if (pc.h_err) (void)hipHostFree(const_cast<unsigned long long*>(pc.h_err));
+    if (pc.shm) munmap(pc.shm, sizeof(PeerShm));
+    pc = PeerComm();
+}
+
+// Bring up the peer-buffer exchange among the `nranks` processes of ONE node: allocate this rank's inbox, publish its
+// hipIpc handle on a shared-memory page named after the communicator id, map everybody else's.
+static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
+    if (nranks > kMaxPeers) return fail(BH_ERR_UNSUPPORTED, "peer-buffer all-reduce supports at most 8 ranks (one node)");
+    PeerComm& pc = g_ctx.peer;
+    unsigned long long h = 1469598103934665603ull;            // FNV-1a of the id: the rendezvous name
+    for (int i = 0; i < BH_UNIQUE_ID_BYTES; ++i) { h ^= id[i]; h *= 1099511628211ull; }
+    char name[64];
+    snprintf(name, sizeof(name), "/bh_ipc_%016llx", h);
+    const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+    if (fd < 0) return fail(BH_ERR_RCCL, std::string("shm_open(") + name + ") failed");
+    if (ftruncate(fd, sizeof(PeerShm)) != 0) { close(fd); return fail(BH_ERR_RCCL, "ftruncate on the rendezvous page failed"); }
+    void* m = mmap(nullptr, sizeof(PeerShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return fail(BH_ERR_RCCL, "mmap of the rendezvous page failed");
+    pc.shm = static_cast<PeerShm*>(m);
+
+    // one allocation = one handle: [slots | flags | seq, arrive].  Fine-grained (uncached) so that a peer's stores and this
+    // rank's polls meet in memory, not in somebody's L2.
+    pc.inbox_bytes = kPeerSlotBytes + kPeerFlagBytes + 256;
+    hipError_t e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&pc.inbox, pc.inbox_bytes); }
+    bool ok = (e == hipSuccess);
+    if (ok) ok = hipMemset(pc.inbox, 0, pc.inbox_bytes) == hipSuccess;
+    char* base = static_cast<char*>(pc.inbox);
+    const unsigned long long one = 1ull;
+    if (ok) ok = hipMemcpy(base + kPeerSlotBytes + kPeerFlagBytes, &one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;   // seq = 1
+    if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+    if (ok && nranks > 1) ok = hipIpcGetMemHandle(&pc.shm->handle[rank], pc.inbox) == hipSuccess;
+    if (!ok) pc.shm->failed = 1;
+    if (!peer_barrier(pc.shm, nranks, 120)) { peer_release(false); return fail(BH_ERR_RCCL, "peer rendezvous: the other ranks did not arrive (same node? same id?)"); }
+    for (int p = 0; p < nranks && !pc.shm->failed; ++p) {
+        if (p == rank) { pc.peer_base[p] = pc.inbox; continue; }
+        if (hipIpcOpenMemHandle(&pc.peer_base[p], pc.shm->handle[p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            pc.peer_base[p] = nullptr;
+            pc.shm->failed = 1;
+        }
+    }
+    const bool met = peer_barrier(pc.shm, nranks, 120);
+    if (rank == 0) shm_unlink(name);           // everybody has mapped the page; nothing is left behind in /dev/shm
+    if (!met || pc.shm->failed) { peer_release(false); return fail(BH_ERR_RCCL, "peer rendezvous: hipIpc handle exchange failed on some rank"); }
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { peer_release(false); return fail(BH_ERR_HIP, "hipHostMalloc(peer error word)"); }
+    memset(hp, 0, 64);
+    pc.h_err = static_cast<volatile unsigned long long*>(hp);
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { peer_release(false); return fail(BH_ERR_HIP, "hipHostGetDevicePointer(peer error word)"); }
+    PeerArgs& a = pc.args;
+    a = PeerArgs{};
+    for (int p = 0; p < nranks; ++p) {
+        char* b = static_cast<char*>(pc.peer_base[p]);
+        a.slots[p] = reinterpret_cast<double*>(b);
+        a.flags[p] = reinterpret_cast<unsigned long long*>(b + kPeerSlotBytes);
+    }
+    a.seq = reinterpret_cast<unsigned long long*>(base + kPeerSlotBytes + kPeerFlagBytes);
+    a.arrive = reinterpret_cast<unsigned*>(base + kPeerSlotBytes + kPeerFlagBytes + 64);
+    a.err = static_cast<unsigned long long*>(dp);
+    a.rank = rank; a.nranks = nranks; a.cap = kPeerCap; a.nblk_cap = kPeerBlkCap;
+    const char* ts = getenv("BH_PEER_TIMEOUT_S");
+    a.timeout_ticks = (unsigned long long)(ts && atof(ts) > 0 ? atof(ts) : 20.0) * 100000000ull;     // wall_clock64: 100 MHz
+    pc.active = true;
+    return BH_OK;
+}
+
 int32_t bh_comm_unique_id(void* id_out) {
     BH_REQUIRE_INIT();
     if (!id_out) return fail(BH_ERR_INVALID_ARG, "NULL id_out");
     static_assert(sizeof(ncclUniqueId) == BH_UNIQUE_ID_BYTES, "ncclUniqueId size");
-    BH_TRY(load_rccl());
-    ncclUniqueId id;
-    BH_NCCL(g_ctx.p_ncclGetUniqueId(&id));
-    memcpy(id_out, &id, sizeof(id));
+    const int mode = comm_mode();
+    if (mode == 0) return fail(BH_ERR_INVALID_ARG, "BH_COMM must be rccl, ipc or both");
+    if (mode & COMM_RCCL) {
+        BH_TRY(load_rccl());
+        ncclUniqueId id;
+        BH_NCCL(g_ctx.p_ncclGetUniqueId(&id));
+        memcpy(id_out, &id, sizeof(id));
+        return BH_OK;
+    }
+    // peer buffers only: the id merely names the rendezvous page
+    unsigned char* o = static_cast<unsigned char*>(id_out);
+    memset(o, 0, BH_UNIQUE_ID_BYTES);
+    FILE* f = fopen("/dev/urandom", "rb");
+    const size_t got = f ? fread(o, 1, 64, f) : 0;
+    if (f) fclose(f);
+    const unsigned long long salt = (unsigned long long)getpid() ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+    memcpy(o + 64, &salt, sizeof(salt));
+    memcpy(o + 72, &got, sizeof(got));
     return BH_OK;
 }
 
 int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id_in) {
     BH_REQUIRE_INIT();
     if (nranks < 1 || rank < 0 || rank >= nranks) return fail(BH_ERR_INVALID_ARG, "bad rank/nranks");
-    if (g_ctx.comm) return fail(BH_ERR_INVALID_ARG, "communicator already initialised");
-    // nranks == 1 needs no communicator; BH_FORCE_COMM=1 creates a 1-rank RCCL communicator anyway so that the whole
-    // RCCL path (dlopen, ncclCommInitRank, ncclAllReduce on the library stream) can be exercised on a one-GPU box.
+    if (comm_active()) return fail(BH_ERR_INVALID_ARG, "communicator already initialised");
+    // nranks == 1 needs no communicator; BH_FORCE_COMM=1 creates a 1-rank communicator anyway so that the whole
+    // exchange path (RCCL: dlopen, ncclCommInitRank, ncclAllReduce on the library stream; peer buffers: inbox, flags,
+    // the fused reduce+exchange kernel) can be exercised and timed on a one-GPU box.
     const char* force = getenv("BH_FORCE_COMM");
     if (nranks == 1 && !(force && atoi(force) != 0)) { g_ctx.rank = 0; g_ctx.nranks = 1; return BH_OK; }
     // a bh_hess bakes in which rank applies the replicated C rows (rank 0): the rank must not change under a live handle
     if (g_ctx.live_hess > 0) return fail(BH_ERR_PRECONDITION, "bh_comm_init: destroy all bh_hess handles first (create them after the communicator)");
     if (!id_in) return fail(BH_ERR_INVALID_ARG, "NULL unique id");
-    BH_TRY(load_rccl());
-    ncclUniqueId id;
-    memcpy(&id, id_in, sizeof(id));
-    BH_NCCL(g_ctx.p_ncclCommInitRank(&g_ctx.comm, nranks, id, rank));
+    const int mode = comm_mode();
+    if (mode == 0) return fail(BH_ERR_INVALID_ARG, "BH_COMM must be rccl, ipc or both");
     g_ctx.rank = rank;
     g_ctx.nranks = nranks;
+    if (mode & COMM_RCCL) {
+        int32_t rc = load_rccl();
+        if (rc == BH_OK) {
+            ncclUniqueId id;
+            memcpy(&id, id_in, sizeof(id));
+            ncclResult_t r = g_ctx.p_ncclCommInitRank(&g_ctx.comm, nranks, id, rank);
+            if (r != ncclSuccess) { g_ctx.comm = nullptr; rc = fail(BH_ERR_RCCL, std::string("ncclCommInitRank: ") + g_ctx.p_ncclGetErrorString(r)); }
+        }
+        if (rc != BH_OK) { g_ctx.rank = 0; g_ctx.nranks = 1; return rc; }
+    }
+    if (mode & COMM_IPC) {
+        const int32_t rc = peer_init(rank, nranks, static_cast<const unsigned char*>(id_in));
+        if (rc != BH_OK) {
+            if (g_ctx.comm && g_ctx.p_ncclCommDestroy) { g_ctx.p_ncclCommDestroy(g_ctx.comm); g_ctx.comm = nullptr; }
+            g_ctx.rank = 0; g_ctx.nranks = 1;
+            return rc;
+        }
+    }
+    g_ctx.comm_path = (mode == COMM_IPC) ? 1 : 0;
     return BH_OK;
 }
 
 int32_t bh_comm_destroy(void) {
-    if (g_ctx.comm && g_ctx.live_hess > 0) return fail(BH_ERR_PRECONDITION, "bh_comm_destroy: destroy all bh_hess handles first");
-    if (g_ctx.comm && g_ctx.p_ncclCommDestroy) {
-        (void)hipStreamSynchronize(g_ctx.stream);
-        g_ctx.p_ncclCommDestroy(g_ctx.comm);
-    }
-    g_ctx.comm = nullptr; g_ctx.rank = 0; g_ctx.nranks = 1;
+    if (comm_active() && g_ctx.live_hess > 0) return fail(BH_ERR_PRECONDITION, "bh_comm_destroy: destroy all bh_hess handles first");
+    if (comm_active() && g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);
+    if (g_ctx.comm && g_ctx.p_ncclCommDestroy) g_ctx.p_ncclCommDestroy(g_ctx.comm);
+    if (g_ctx.peer.active) peer_release(true);
+    g_ctx.comm = nullptr; g_ctx.rank = 0; g_ctx.nranks = 1; g_ctx.comm_path = 0;
     return BH_OK;
 }
 
@@ -924,6 +1172,7 @@ int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int
     int32_t rc = alloc_hess_common(H);
     if (rc == BH_OK) rc = upload_transposed(J, d, n, ldJ, H->Jd, 0, H->ld);
     if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
+    if (rc == BH_OK) rc = finish_hess_create(H);
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     BH_TRY(sync_flush());
     *out = H;
@@ -946,6 +1195,7 @@ int32_t bh_hess_create_dev(bh_hess** out, const double* J_dev, int64_t d, int64_
     if (rc == BH_OK) rc = transpose_from_device(J_dev, d, n, ldJ, H->Jd, 0, H->ld);
     if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
     if (rc == BH_OK && hipStreamSynchronize(g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "bh_hess_create_dev: synchronize");
+    if (rc == BH_OK) rc = finish_hess_create(H);
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     *out = H;
     H->counted = true;
@@ -975,6 +1225,8 @@ int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t ro
     hipError_t e = hipStreamSynchronize(g_ctx.stream);
     dev_free(cs_dev);
     if (e != hipSuccess) { bh_hess_destroy(H); return fail(BH_ERR_HIP, std::string("synth_fill: ") + hipGetErrorString(e)); }
+    rc = finish_hess_create(H);
+    if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     *out = H;
     H->counted = true;
     g_ctx.live_hess += 1;
@@ -1224,12 +1476,16 @@ struct PcgFin { int done, status, iter, n_hmul; };
 // Measured at config 3 "ic" (23 iterations of 315 us): 7.247 ms per subproblem at batch 1, 7.281 at 4, 7.775 at 64.
 static int launch_batch_size(const bh_hess* H) {
     if (g_ctx.opt_batch > 0) return (int)g_ctx.opt_batch;
-    const double est_us = H->stats.bytes_per_hmul / 7.0e6;      // ~7 TB/s streaming rate
+    // rank-independent on purpose (see finish_hess_create): the even share of the rows over all ranks plus the full C
+    // block, not this rank's own d + q_eff
+    const double rows = (double)((H->d_total + g_ctx.nranks - 1) / g_ctx.nranks + H->q);
+    const double est_us = (multi_panel(H) ? 16.0 : 8.0) * rows * (double)H->n / 7.0e6;      // ~7 TB/s streaming rate
     return est_us >= 100.0 ? 1 : est_us >= 40.0 ? 2 : 4;
 }
 // The first batch is sized by the previous call on the handle (consecutive subproblems of a minor loop behave alike):
 // an exact prediction means no gated launches and no host round trip inside the loop at all.
 constexpr int kFirstBatchCap = 32;
+constexpr int kFirstBatchCapRccl = 8;
 
 // Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
 // still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
@@ -1310,7 +1566,9 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // while launch-ahead batches run).  done_by(target) is that rank-independent predicate.
     MirrorWord mw{};
     auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
-    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : std::min(batch, 2);
+    // (an RCCL all-reduce cannot be gated from the device: every over-launched iteration pays for one, so predict less boldly)
+    const int first_cap = (comm_active() && !use_peer_path()) ? kFirstBatchCapRccl : kFirstBatchCap;
+    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, first_cap) : std::min(batch, 2);
     BH_TRY(launch_batch(first));
     BH_TRY(wait_mirror(c, a.tag, launched, &mw));
     if (!done_by(launched) && launched < max_iter) {
@@ -1334,6 +1592,12 @@ static int32_t pcg_finish(bh_hess* H, const PcgFin& fin) {
     if (!fin.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
     H->stats.n_pcg += 1;
     H->last_n_hmul = fin.n_hmul;
+    {   // the tie log the final publish_state left next to the progress word (the stream has been drained)
+        const unsigned long long tw = g_ctx.cg.h_mirror[1], mb = g_ctx.cg.h_mirror[2];
+        H->margin_kind = (int)((tw >> 48) & 0xf); H->tie_flags = (int)((tw >> 40) & 0xff);
+        H->tie_first = (int)((tw >> 20) & 0xfffff); H->margin_at = (int)(tw & 0xfffff);
+        memcpy(&H->min_margin, &mb, sizeof(double));
+    }
     H->stats.n_hmul += fin.n_hmul;
     H->stats.n_cg_iter += fin.iter - 1;
     H->stats.n_proj += fin.iter;
@@ -1392,6 +1656,17 @@ int32_t bh_pcg(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l,
                double atol_negcurv, double atol_f2b, double* w_out, int32_t* status, int32_t* iters, double* trace,
                int64_t trace_cap, int32_t* n_hmul) {
     return pcg_impl(H, P, g_minor, w_l, w_u, kappa2, atol_negcurv, atol_f2b, w_out, status, iters, trace, trace_cap, n_hmul, false);
+}
+
+int32_t bh_pcg_tie_info(const bh_hess* H, int32_t* tie_flags, int32_t* first_tie_hmul, double* min_margin, int32_t* min_margin_kind,
+                        int32_t* min_margin_hmul) {
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    if (tie_flags) *tie_flags = H->tie_flags;
+    if (first_tie_hmul) *first_tie_hmul = H->tie_first;
+    if (min_margin) *min_margin = H->min_margin;
+    if (min_margin_kind) *min_margin_kind = H->margin_kind;
+    if (min_margin_hmul) *min_margin_hmul = H->margin_at;
+    return BH_OK;
 }
 
 int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const double* w_l_dev, const double* w_u_dev, double kappa2,
@@ -1492,6 +1767,27 @@ int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out) 
     BH_TRY(fetch_vec(g_out, H->zpad, H->n, false));
     BH_TRY(sync_flush());
     H->stats.n_jtv += 1;
+    return BH_OK;
+}
+
+// dot(rx, rx) of mx = 0.5*dot(rx,rx) + ... — src/basic_tralcnlss.jl:44 (new_point), :58 (evaluate_al): r = this rank's rows of
+// the residual; the partial sums of squares are all-reduced (rank order), so every rank gets the same bits.
+int32_t bh_resid_sqnorm(const double* r, int64_t d, double* out) {
+    BH_REQUIRE_INIT();
+    if (d < 0 || (!r && d > 0) || !out) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    if (d + 4 > g_ctx.rbuf_cap) {
+        dev_free(g_ctx.rbuf);
+        g_ctx.rbuf = nullptr; g_ctx.rbuf_cap = 0;
+        BH_TRY(dev_alloc(&g_ctx.rbuf, d + 4));
+        g_ctx.rbuf_cap = d + 4;
+    }
+    double* acc = g_ctx.rbuf + round_up(d, 2);   // 2 doubles, 16-byte aligned: the exchange works on whole chunks
+    BH_TRY(stage_vec(g_ctx.rbuf, r, d, false));
+    hipLaunchKernelGGL(weighted_sqsum_kernel, dim3(1), dim3(1024), 0, g_ctx.stream, (const double*)g_ctx.rbuf, d, d, 1.0, acc);
+    BH_HIP(hipGetLastError());
+    BH_TRY(allreduce_inplace(acc, 1, nullptr));
+    BH_TRY(fetch_vec(out, acc, 1, false));
+    BH_TRY(sync_flush());
     return BH_OK;
 }
 
@@ -1694,10 +1990,31 @@ int32_t bh_stats_reset(bh_hess* H) {
 
 int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
     BH_REQUIRE_INIT();
-    if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 6) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 8) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    if (kind == 7 && !comm_active()) return fail(BH_ERR_PRECONDITION, "bh_time_kernel(7): no communicator (bh_comm_init; BH_FORCE_COMM=1 for one rank)");
     hipEvent_t e0, e1;
     BH_HIP(hipEventCreate(&e0));
     BH_HIP(hipEventCreate(&e1));
+    if (kind >= 7) {
+        // 7: the all-reduce of one n-vector on the active communicator path; 8: everything an H*p does after its streaming
+        // kernel (slab reduction + exchange).  Back-to-back launches between two events: all ranks must call this together.
+        const int cfg = multi_panel(H) ? kPanelCfg : pick_config(H->nchunks);
+        const int grid = grid_for(cfg, H->d + H->q_eff);
+        int32_t rc = BH_OK;
+        for (int i = 0; i < 3 && rc == BH_OK; ++i) rc = (kind == 7) ? allreduce_inplace(H->zpad, H->n, nullptr) : reduce_slabs(H, grid, H->zpad, nullptr);
+        if (rc == BH_OK && hipEventRecord(e0, g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "hipEventRecord");
+        for (int i = 0; i < reps && rc == BH_OK; ++i) rc = (kind == 7) ? allreduce_inplace(H->zpad, H->n, nullptr) : reduce_slabs(H, grid, H->zpad, nullptr);
+        if (rc == BH_OK && hipEventRecord(e1, g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "hipEventRecord");
+        if (rc == BH_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(BH_ERR_HIP, "hipEventSynchronize");
+        float ms = 0.f;
+        if (rc == BH_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BH_ERR_HIP, "hipEventElapsedTime");
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (rc == BH_OK) rc = check_peer_error();
+        if (rc != BH_OK) return rc;
+        *avg_ms = ms / reps;
+        return BH_OK;
+    }
     if (kind >= 3) {
         // read-only stream probe over the (d + q) x ld image: 1, 2, 4 or 8 workgroups per CU
         const int grid = g_ctx.n_cu * (1 << (kind - 3));

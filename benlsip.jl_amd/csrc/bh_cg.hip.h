@@ -58,6 +58,12 @@ __device__ __forceinline__ void publish_state(const CgArgs& a, const CgState* st
     const unsigned long long wv = ((unsigned long long)(a.tag & 0xffffu) << 48) | ((unsigned long long)(st->status & 0xf) << 44) |
                                   ((unsigned long long)(st->done & 0xf) << 40) | ((unsigned long long)(st->iter & 0xfffff) << 20) |
                                   (unsigned long long)(st->n_hmul & 0xfffff);
+    if (st->done) {   // the tie log of the finished call: read by the host after it has drained the stream
+        const unsigned long long tw = ((unsigned long long)(st->margin_kind & 0xf) << 48) | ((unsigned long long)(st->tie_flags & 0xff) << 40) |
+                                      ((unsigned long long)(st->tie_first & 0xfffff) << 20) | (unsigned long long)(st->margin_at & 0xfffff);
+        __hip_atomic_store(a.mirror + 1, tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(a.mirror + 2, (unsigned long long)__double_as_longlong(st->min_margin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __hip_atomic_store(a.mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -94,6 +100,7 @@ __global__ __launch_bounds__(CG_T) void cg_init_kernel(CgArgs a) {
             st->iter = 1; st->max_iter = a.max_iter;
             st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
             st->n_hmul = 0; st->need_proj = 0;
+            tie_reset(st);
             st->done = (1 <= a.max_iter) ? 0 : 1;   // :720
             st->status = cg_final_status(st);
             publish_state(a, st);
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(CG_T) void cg_init_finish_kernel(CgArgs a) {
         st->iter = 1; st->max_iter = a.max_iter;
         st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
         st->n_hmul = 0; st->need_proj = 0;
+        tie_reset(st);
         st->done = (1 <= a.max_iter) ? 0 : 1;
         st->status = cg_final_status(st);
         publish_state(a, st);
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
             st->pHp = pHp; st->gamma = gamma; st->alpha = (pHp <= a.atol_neg) ? __longlong_as_double(0x7ff8000000000000ll) : alpha;
             st->n_hmul += 1;
             st->neg_curvature = neg; st->outside_region = outside;
+            tie_note_step_a(st, pHp, a.atol_neg, alpha, gamma, st->n_hmul);
             if (!cont) {
                 st->done = 1; st->need_proj = 0;
                 st->status = cg_final_status(st);
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
             if (tid == 0) {
                 st->beta = beta; st->rtv = rtv_next;            // :746
                 st->approx_solved = fabs(rtv_next) < st->tol_cg;   // :747
+                tie_note(st, TIE_TOL, rel_margin(fabs(rtv_next), st->tol_cg), st->n_hmul);
                 st->iter += 1;                                  // :748
                 st->need_proj = 0;
                 if (st->approx_solved || st->iter > st->max_iter) { st->done = 1; st->status = cg_final_status(st); }
@@ -237,6 +247,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_kernel(CgArgs a) {
         if (tid == 0) {
             st->beta = beta; st->rtv = rtv_next;
             st->approx_solved = fabs(rtv_next) < st->tol_cg;
+            tie_note(st, TIE_TOL, rel_margin(fabs(rtv_next), st->tol_cg), st->n_hmul);
             st->iter += 1;
             st->need_proj = 0;
             if (st->approx_solved || st->iter > st->max_iter) { st->done = 1; st->status = cg_final_status(st); }
@@ -439,10 +450,12 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         if (FIRST) {
             st->rtv = rtv; st->tol_cg = tol_cg; st->beta = 0.0;
             st->iter = 1; st->max_iter = max_iter; st->approx_solved = 0; st->done = 0; st->status = 4;
+            tie_reset(st);
         }
         if (PHASE != 2) {
             st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = n_hmul;
             st->neg_curvature = neg; st->outside_region = outside;
+            tie_note_step_a(st, pHp, a.atol_neg, alpha, gamma, n_hmul);
             st->need_proj = (PHASE == 1 && cont) ? 1 : 0;
             if (!cont) {
                 st->done = 1;
@@ -453,6 +466,7 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
         if (cont && PHASE != 1) {
             st->beta = beta; st->rtv = rtv_next;                           // :746
             st->approx_solved = fabs(rtv_next) < tol_cg;                   // :747
+            tie_note(st, TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), n_hmul);
             st->iter = iter0 + 1;                                          // :748
             st->need_proj = 0;
             if (st->approx_solved || st->iter > max_iter) { st->done = 1; st->status = cg_final_status(st); }

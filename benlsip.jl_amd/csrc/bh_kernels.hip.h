@@ -21,3 +21,4 @@
 #include "bh_cg.hip.h"
 #include "bh_proj.hip.h"
 #include "bh_cauchy.hip.h"
+#include "bh_comm.hip.h"

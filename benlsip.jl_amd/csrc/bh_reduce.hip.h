@@ -88,7 +88,37 @@ struct CgState {
     int n_hmul;      // H*p products performed
     int need_proj;   // general path: step_a decided to continue -> projection + step_b run
     int pad;
+    // Tie log: how close the loop's branch scalars came to their thresholds in this call.
+    double min_margin;   // smallest relative distance |a - b| / max(|a|, |b|) of any branch test to its threshold
+    int margin_kind;     // which test that was (TIE_*)
+    int margin_at;       // ... at which H*p product
+    int tie_flags;       // TIE_* bits of the tests that came within kTieRel of their threshold
+    int tie_first;       // first H*p product at which that happened (0: never)
 };
+
+// Branch tests of projected_cg whose outcome can flip under rounding (src/basic_tralcnlss.jl:725, :727, :735, :747).
+enum { TIE_NEGCURV = 1, TIE_NEGCURV_ABS = 2, TIE_BOUND = 4, TIE_TOL = 8 };
+constexpr double kTieRel = 1e-10;
+
+__device__ __forceinline__ double rel_margin(double a, double b) {
+    const double m = fmax(fabs(a), fabs(b));
+    if (!(m < __longlong_as_double(0x7ff0000000000000ll))) return (a == b) ? 0.0 : 1.0;   // an infinite operand: far, unless both are the same infinity
+    return m > 0.0 ? fabs(a - b) / m : 0.0;
+}
+__device__ __forceinline__ void tie_reset(CgState* st) {
+    st->min_margin = __longlong_as_double(0x7ff0000000000000ll);
+    st->margin_kind = 0; st->margin_at = 0; st->tie_flags = 0; st->tie_first = 0;
+}
+__device__ __forceinline__ void tie_note(CgState* st, int kind, double margin, int n_hmul) {
+    if (margin < st->min_margin) { st->min_margin = margin; st->margin_kind = kind; st->margin_at = n_hmul; }
+    if (margin <= kTieRel) { st->tie_flags |= kind; if (st->tie_first == 0) st->tie_first = n_hmul; }
+}
+// After step_a's branch (:725-739): pHp against tol_negcurve, |pHp| against it again, alpha against gamma.
+__device__ __forceinline__ void tie_note_step_a(CgState* st, double pHp, double atol_neg, double alpha, double gamma, int n_hmul) {
+    tie_note(st, TIE_NEGCURV, rel_margin(pHp, atol_neg), n_hmul);
+    if (pHp <= atol_neg) tie_note(st, TIE_NEGCURV_ABS, rel_margin(fabs(pHp), atol_neg), n_hmul);
+    else tie_note(st, TIE_BOUND, rel_margin(alpha, gamma), n_hmul);
+}
 
 // Self-test of the wave reduction network (bh_selftest): out[wave] = sum, out[16 + wave] = min.
 __global__ __launch_bounds__(256) void selftest_wave_kernel(const double* in, double* out) {

@@ -324,6 +324,20 @@ def factor_to_boundary(p, w, w_l, w_u, atol=1e-10):
     return out.value
 
 
+TIE_KINDS = {1: "pHp<=tol_negcurve (:725)", 2: "|pHp|>tol (:727)", 4: "alpha>gamma (:735)", 8: "|rtv|<tol_cg (:747)"}
+
+
+def tie_info(H):
+    """Tie log of the last ``projected_cg`` on ``H`` (``bh_pcg_tie_info``): which branch tests came within
+    1e-10 (relative) of their threshold, and the closest any test came in that call."""
+    flags, first, kind, at = ct.c_int32(0), ct.c_int32(0), ct.c_int32(0), ct.c_int32(0)
+    margin = ct.c_double(0.0)
+    check(_lib.lib().bh_pcg_tie_info(H.handle, ct.byref(flags), ct.byref(first), ct.byref(margin), ct.byref(kind), ct.byref(at)),
+          "bh_pcg_tie_info")
+    return {"tie_flags": flags.value, "first_tie_hmul": first.value, "min_margin": margin.value,
+            "min_margin_kind": kind.value, "min_margin_hmul": at.value}
+
+
 def projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, atol=SQRT_EPS, atol_f2b=1e-10, trace_cap=0, full_output=False):
     """``projected_cg(g_minor, H, w_l, w_u, lincons, kappa2; atol)`` — src/basic_tralcnlss.jl:690-764.
 
@@ -341,7 +355,7 @@ def projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, atol=SQRT_EPS, atol_f2b=
     st = CGStatus(status.value)
     if full_output:
         info = {"iters": iters.value, "n_hmul": n_hmul.value,
-                "trace": None if trace is None else trace[:min(trace_cap, n_hmul.value)]}
+                "trace": None if trace is None else trace[:min(trace_cap, n_hmul.value)], "ties": tie_info(H)}
         return w, st, info
     return w, st
 
@@ -367,7 +381,7 @@ def minor_iterate(x, s, g_model, H, lincons, delta, kappa2, atol=SQRT_EPS, atol_
                                       ct.byref(iters), ct.byref(n_hmul), ct.byref(alpha)), "bh_minor_iterate")
     st = CGStatus(status.value)
     if full_output:
-        return w, st, {"iters": iters.value, "n_hmul": n_hmul.value, "alpha": alpha.value}
+        return w, st, {"iters": iters.value, "n_hmul": n_hmul.value, "alpha": alpha.value, "ties": tie_info(H)}
     return w, st
 
 
@@ -400,6 +414,19 @@ def gradient(H, rx, y_bar=None):
     out = np.empty(H.n)
     check(_lib.lib().bh_grad(H.handle, ptr(r), ptr(yb), ptr(out)), "bh_grad")
     return out
+
+
+def resid_sqnorm(rx):
+    """``dot(rx, rx)`` of ``mx = 0.5*dot(rx,rx) + ...`` — src/basic_tralcnlss.jl:44,:58; ``rx`` = this rank's rows, the
+    result is the global value (all-reduced), identical on every rank."""
+    r = as_f64(rx)
+    out = ct.c_double(0.0)
+    check(_lib.lib().bh_resid_sqnorm(ptr(r), r.shape[0], ct.byref(out)), "bh_resid_sqnorm")
+    return out.value
+
+
+def set_option(key, value):
+    check(_lib.lib().bh_set_option(key.encode(), int(value)), "bh_set_option(%s)" % key)
 
 
 def hmul_add(H, s, g):

@@ -90,7 +90,15 @@ int32_t bh_device_info(char* name_out, int64_t name_cap, int32_t* n_cu, char* ar
 #define BH_UNIQUE_ID_BYTES 128
 /* rank 0 creates the id, the host runtime (torch.distributed, MPI, a Julia Distributed channel) broadcasts it. */
 int32_t bh_comm_unique_id(void* id_out /* BH_UNIQUE_ID_BYTES */);
-/* Both return BH_ERR_PRECONDITION while any bh_hess handle is alive: a handle records at creation whether THIS rank applies
+/* Two interchangeable transports for the one exchange on the path (the sum over ranks of an n-vector per J'·), chosen by the
+ * environment variable BH_COMM when the communicator is created:
+ *   "rccl" (default)  ncclAllReduce(n doubles, sum) on the library stream.
+ *   "ipc"             one-shot exchange over peer-mapped buffers (hipIpc; ranks of ONE node, <= 8): every rank pushes its
+ *                     partial into all inboxes and sums what it received in rank order — one hop instead of a ring, fused
+ *                     into the kernel that reduces the per-workgroup slabs, bit-identical on all ranks by construction, and
+ *                     skipped on the device by over-launched (already finished) CG iterations.  Needs no librccl.
+ *   "both"            both are brought up; bh_set_option("comm_path", 0|1) switches (default RCCL).
+ * Both return BH_ERR_PRECONDITION while any bh_hess handle is alive: a handle records at creation whether THIS rank applies
  * the replicated C rows (rank 0 does), so the rank must not change under it.  Order: bh_init, bh_comm_init, create handles,
  * ..., destroy handles, bh_comm_destroy.  (nranks == 1 creates no communicator and is always accepted.)
  * BH_RCCL_LIB (environment) names the librccl to load; default: the copy already mapped into the process, else the system one. */
@@ -170,6 +178,19 @@ int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const doub
                    double kappa2, double atol_negcurv, double atol_f2b,
                    double* w_out_dev, int32_t* status, int32_t* iters,
                    double* trace, int64_t trace_cap, int32_t* n_hmul);
+/* Tie log of the LAST projected_cg run on this handle (bh_pcg, bh_pcg_dev, bh_minor_iterate) — SURVEY.md §8(c): the loop's
+ * branches (src/basic_tralcnlss.jl:725 pHp <= tol_negcurve, :727 |pHp| > tol, :735 alpha > gamma, :747 |rtv| < tol_cg) decide
+ * status and iteration count, so a scalar within rounding of its threshold may legitimately flip against another
+ * implementation.  tie_flags: BH_TIE_* bits of the tests that came within 1e-10 (relative) of their threshold;
+ * first_tie_hmul: the H*p product at which that first happened (0 = never); min_margin / _kind / _hmul: the smallest
+ * relative distance |a-b|/max(|a|,|b|) any of those tests had in the call, which test, and at which product. */
+#define BH_TIE_NEGCURV      1   /* :725 */
+#define BH_TIE_NEGCURV_ABS  2   /* :727 */
+#define BH_TIE_BOUND        4   /* :735 */
+#define BH_TIE_TOL          8   /* :747 */
+int32_t bh_pcg_tie_info(const bh_hess* H, int32_t* tie_flags, int32_t* first_tie_hmul, double* min_margin,
+                        int32_t* min_margin_kind, int32_t* min_margin_hmul);
+
 /* ---- callers of projected_cg, device-resident (SURVEY.md §8 a9, a10 and "next" row f-2) ----------------- */
 
 /* minor_iterate(x, s, g_model, H, lincons, delta, kappa2) — src/basic_tralcnlss.jl:649-675: builds w_l/w_u exactly as :660-665
@@ -195,6 +216,11 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
                        double delta, double* s_out, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul);
 /* g = Jx'*rx + Cx'*y_bar — src/basic_tralcnlss.jl:45 (new_point), :74 (first_derivatives); r = this rank's d rows, y_bar has q entries. */
 int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out);
+/* dot(rx,rx) of the augmented-Lagrangian value mx = 0.5*dot(rx,rx) + dot(y,cx) + 0.5*mu*dot(cx,cx) — src/basic_tralcnlss.jl:44
+ * (new_point) and :58 (evaluate_al).  r = this rank's d rows of the residual; the ranks' partial sums are all-reduced in rank
+ * order, so out is the GLOBAL squared norm, bit-identical on every rank (with one rank: plain dot(r,r)).  Row-sharded callers
+ * need it to keep the replicated trust-region control flow (rho = ared/pred, :353-358) in lock-step. */
+int32_t bh_resid_sqnorm(const double* r, int64_t d, double* out);
 /* g_minor = H*s + g — src/basic_tralcnlss.jl:412,:437. */
 int32_t bh_hmul_add(bh_hess* H, const double* s, const double* g, double* out_n);
 
@@ -221,12 +247,17 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "rs_variant"     [0] A/B geometries of the row-streaming kernel for 2048 < n <= 4096 (tools/kernel_ab.py)
  *   "blocks_per_cu"  [0] workgroups per CU of the row-streaming kernels (0: per-geometry default)
  *   "pingpong"       [0] alternate the sweep direction of J between consecutive H*p
+ *   "blocks_per_cu" accepts 0..8 (the partial-slab buffers hold 8 workgroups per CU); anything else is BH_ERR_INVALID_ARG
+ *   "comm_path"      [0 with BH_COMM=rccl|both, 1 with BH_COMM=ipc] which communicator carries the all-reduces: 0 = RCCL,
+ *                        1 = the one-shot peer-buffer exchange fused into the slab reduction (needs BH_COMM=ipc or both)
  *   "profile"        [flags of bh_init] 1 = hipEvents around every 8th H*p launch (bh_stats: hmul_ms / hmul_timed) */
 int32_t bh_set_option(const char* key, int64_t value);
 /* Time `reps` back-to-back launches of one kernel class with hipEvents on the launch stream.
  * kind: 0 = fused J'(Jp), 1 = J·v, 2 = J'·u; 3..6 = read-only stream probe over the same image (nothing but 16-byte
  * non-temporal loads and adds) with 1, 2, 4, 8 workgroups per CU: the practical single-read ceiling the kernels are
- * quoted against.  Returns the average milliseconds per launch. */
+ * quoted against; 7 = the all-reduce of one n-vector on the active communicator path (every rank must call it together);
+ * 8 = everything an H*p does after its streaming kernel (slab reduction + all-reduce; without a communicator: the slab
+ * reduction alone).  Returns the average milliseconds per launch. */
 int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms);
 /* Device self-test of the wave64 DPP/permlane reduction network (sum and NaN-propagating min). */
 int32_t bh_selftest(void);

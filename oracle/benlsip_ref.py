@@ -359,6 +359,25 @@ class NumpyOps:
         w, status, _ = projected_cg(g_minor, H, w_l, w_u, lincons, kappa2)
         return w, status
 
+    # The three places where the callers touch the residual rows directly.  A row-sharded backend (one rank holds
+    # rows [lo, hi) of r and J) overrides them with all-reduced forms; here they are the reference's own expressions.
+    def residual_sqnorm(self, rx):
+        """``dot(rx,rx)`` in ``mx`` — src/basic_tralcnlss.jl:44 (new_point), :58 (evaluate_al)."""
+        return float(np.dot(rx, rx))
+
+    def gradient(self, H, Jx, rx, Cx, y_bar):
+        """``g = Jx'*rx + Cx'*y_bar`` — src/basic_tralcnlss.jl:45 (new_point), :74 (first_derivatives)."""
+        return Jx.T @ rx + Cx.T @ y_bar
+
+    def jtr(self, J, r):
+        """``jac_res(x)' * residuals(x)`` — src/basic_tralcnlss.jl:893 (least_squares_multipliers)."""
+        return J.T @ r
+
+
+def _hook(ops, name):
+    """Backends written before a hook existed fall back to the reference expression."""
+    return getattr(ops, name, None) or getattr(NumpyOps(), name)
+
 
 def build_step_bounds(x_minor, lincons: MixedConstraints, delta: float):
     """The ``w_l``/``w_u`` construction of ``minor_iterate`` —
@@ -468,8 +487,6 @@ def inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa
             w, cg_status = ops.minor_iterate(x, s, g_minor, H, lincons, delta, kappa2)
         else:
             w, cg_status = minor_iterate(x, s, g_minor, H, lincons, delta, kappa2, ops)
-        if log is not None:
-            log.append(("minor", int(cg_status)))
         cg_stop = cg_status == CGStatus.negative_curvature
         s = s + w                                                  # :436
         g_minor = hmul_add(H, s, g)                                # :437
@@ -482,6 +499,10 @@ def inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa
         else:
             approx_solved = True
             active_bounds_inplace(lincons, x + s, chol_aat_L)      # :452
+        if log is not None:
+            # (tag, CG status, active bounds after the update, the ratio the loop's exit test compares with 1 (:449))
+            log.append(("minor", int(cg_status), nb_fix(lincons),
+                        norm_reduced_g_minor / (kappa3 * norm_reduced_g) if norm_reduced_g > 0 else math.inf))
         j += 1
     model_reduction = float(np.dot(g, s)) + 0.5 * ops.vthv(H, s)   # :458
     return s, model_reduction
@@ -508,12 +529,13 @@ def solve_subproblem(x0, y, mu, residuals, nlconstraints, jac_res, jac_nlcons, c
     first_derivatives :63-77, second_derivatives :79-85)."""
     ops = ops or NumpyOps()
     x = np.array(x0, dtype=np.float64, copy=True)
+    sqnorm, gradient = _hook(ops, "residual_sqnorm"), _hook(ops, "gradient")
     rx, cx = residuals(x), nlconstraints(x)
     Jx, Cx = jac_res(x), jac_nlcons(x)
     y_bar = y + mu * cx
-    mx = 0.5 * np.dot(rx, rx) + np.dot(y, cx) + 0.5 * mu * np.dot(cx, cx)
-    g = Jx.T @ rx + Cx.T @ y_bar
-    H = ops.new_hessian(Jx, Cx, mu)
+    mx = 0.5 * sqnorm(rx) + np.dot(y, cx) + 0.5 * mu * np.dot(cx, cx)    # :44
+    H = ops.new_hessian(Jx, Cx, mu)                                      # :46 (built first so a device backend can use it for g)
+    g = gradient(H, Jx, rx, Cx, y_bar)                                   # :45
     pix = math.inf
     delta = initial_tr(g)
     k = 1
@@ -522,7 +544,7 @@ def solve_subproblem(x0, y, mu, residuals, nlconstraints, jac_res, jac_nlcons, c
         s, pred = inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa3, ops, log)
         x_next = x + s
         rx_next, cx_next = residuals(x_next), nlconstraints(x_next)
-        mx_next = 0.5 * np.dot(rx_next, rx_next) + np.dot(y, cx_next) + 0.5 * mu * np.dot(cx_next, cx_next)
+        mx_next = 0.5 * sqnorm(rx_next) + np.dot(y, cx_next) + 0.5 * mu * np.dot(cx_next, cx_next)   # :58
         ared = mx_next - mx
         with np.errstate(all="ignore"):
             rho = ared / pred
@@ -531,18 +553,24 @@ def solve_subproblem(x0, y, mu, residuals, nlconstraints, jac_res, jac_nlcons, c
             rx, cx, mx = rx_next, cx_next, mx_next
             Jx, Cx = jac_res(x), jac_nlcons(x)
             y_bar = y + mu * cx
-            g = Jx.T @ rx + Cx.T @ y_bar
-            H = ops.new_hessian(Jx, Cx, mu)
+            H = ops.new_hessian(Jx, Cx, mu)                              # :84
+            g = gradient(H, Jx, rx, Cx, y_bar)                           # :74
         delta = update_tr(delta, rho, eta1, eta2, gamma1, gamma2)
         pix = norm_reduced_gradient(g, lincons, ops)               # :369
         solved = pix < omega_tol
+        if log is not None:
+            # (tag, rho, pix/omega, new delta, ared, pred, |mx|): rho = ared/pred (:353-354) is the ratio of a difference of two
+            # nearly equal objective values to a tiny model reduction once the steps get small — the log keeps the operands
+            # so that a reader can tell a rounding-dominated rho (|ared| ~ eps*|mx|) from a real disagreement
+            log.append(("tr", float(rho), float(pix / omega_tol) if omega_tol > 0 else math.inf, float(delta),
+                        float(ared), float(pred), float(max(abs(mx), abs(mx_next)))))
         k += 1
     return x, cx, pix
 
 
-def least_squares_multipliers(x, residuals, jac_res, jac_nlcons):
+def least_squares_multipliers(x, residuals, jac_res, jac_nlcons, ops=None):
     """src/basic_tralcnlss.jl:887-903."""
-    g = jac_res(x).T @ residuals(x)
+    g = _hook(ops or NumpyOps(), "jtr")(jac_res(x), residuals(x))       # :893
     C = jac_nlcons(x)
     L = chol_lower(C @ C.T)
     b = -C @ g
@@ -566,7 +594,7 @@ def tralcnllss(x0, residuals, jac_res, nlconstraints, jac_nlcons, A, b, x_l, x_u
     mu = mu0
     omega = omega0 / (mu0 ** k_crit)                               # :153-163
     eta = eta0 / (mu0 ** k_feas)
-    y = least_squares_multipliers(x, residuals, jac_res, jac_nlcons)
+    y = least_squares_multipliers(x, residuals, jac_res, jac_nlcons, ops)
     polyhedron = make_mixed_constraints(A, chol_aat_L, l=x_l, u=x_u)
     first_order_critical = False
     outer_iter = 1

@@ -1,0 +1,177 @@
+"""Backends ("ops") that plug the C ABI into the oracle's restated outer iteration (tralcnllss -> solve_subproblem ->
+inner_step -> minor_iterate), the executable stand-in for the unchanged Julia driver: every hot-path call goes through the
+library exactly as julia/BEnlsipHIP.jl routes it.  Test infrastructure (imports the oracle for its CGStatus enum and for the
+shadow comparison)."""
+import numpy as np
+
+import benlsip_ref as R
+
+
+class HipOps:
+    """`*`, vthv, projection!, projected_cg on the device (the minimal shim: SURVEY.md §8 a2-a8)."""
+
+    def __init__(self, bh):
+        self.bh = bh
+        self.n_pcg = 0
+        self.ties = []                 # (minor-iterate index, tie info) of every projected_cg whose tie log is not empty
+
+    def new_hessian(self, J, C, mu):
+        return self.bh.AlHessian(J, C, mu)
+
+    def hmul(self, H, v):
+        return self.bh.hmul(H, v)
+
+    def vthv(self, H, v):
+        return self.bh.vthv(H, v)
+
+    def _dev(self, lincons):
+        dev = getattr(lincons, "_dev", None)
+        if dev is None:
+            dev = self.bh.MixedConstraints(lincons.lineq, None, None, l=lincons.xlow, u=lincons.xupp)
+            lincons._dev = dev
+        dev.set_active(lincons.fixvars, lincons.chol_L)
+        return dev
+
+    def projection(self, lincons, r):
+        return self.bh.projection(self._dev(lincons), r)
+
+    def _note(self, info):
+        t = info.get("ties")
+        if t is not None:
+            self.last_ties = t
+            if t["tie_flags"]:
+                self.ties.append((self.n_pcg, t))
+
+    def projected_cg(self, g_minor, H, w_l, w_u, lincons, kappa2):
+        self.n_pcg += 1
+        w, status, info = self.bh.projected_cg(g_minor, H, w_l, w_u, self._dev(lincons), kappa2, full_output=True)
+        self.last_iters = info["iters"]
+        self._note(info)
+        return w, R.CGStatus(int(status))
+
+
+class HipOpsDeviceMinor(HipOps):
+    """Same, with the whole minor iterate (step bounds + projected_cg + linesearch + scaling) and H*s+g on the device
+    (bh_minor_iterate, bh_hmul_add: SURVEY.md §8 a10 / f-2)."""
+
+    def minor_iterate(self, x, s, g_model, H, lincons, delta, kappa2):
+        self.n_pcg += 1
+        w, status, info = self.bh.minor_iterate(x, s, g_model, H, self._dev(lincons), delta, kappa2, full_output=True)
+        self.last_iters = info["iters"]
+        self._note(info)
+        return w, R.CGStatus(int(status))
+
+    def hmul_add(self, H, s, g):
+        return self.bh.hmul_add(H, s, g)
+
+
+class HipOpsDeviceAll(HipOpsDeviceMinor):
+    """Same, plus the Cauchy search on the device (bh_cauchy_step); the oracle-side lincons is brought
+    to the state the reference's cauchy_step leaves behind (fixvars + refreshed factor)."""
+
+    def cauchy_step(self, x, g, H, chol_aat_L, lincons, delta):
+        dev = self._dev(lincons)
+        s = self.bh.cauchy_step(x, g, H, dev, delta)
+        lincons.fixvars = dev.fixvars.copy()
+        R.update_chol(lincons, chol_aat_L)
+        return s
+
+
+class ShardedHipOps(HipOpsDeviceAll):
+    """Row-sharded run: this rank's `residuals` / `jac_res` callbacks return rows [lo, hi) only, the
+    library's communicator is up, and the three places where the driver touches residual rows directly — mx (:44,:58),
+    g (:45,:74) and the least-squares multipliers' J'r (:893) — are routed to their all-reduced entry points, as the
+    multi-rank methods of julia/BEnlsipHIP.jl do.  Everything else is replicated and must stay bit-identical."""
+
+    def residual_sqnorm(self, rx):
+        return self.bh.resid_sqnorm(rx)
+
+    def gradient(self, H, Jx, rx, Cx, y_bar):
+        return self.bh.gradient(H, rx, y_bar)
+
+    def jtr(self, J, r):
+        H = self.bh.AlHessian(J, None, 0.0)
+        try:
+            return H.jtv(r)
+        finally:
+            H.close()
+
+
+class ShadowOps:
+    """Runs the device backend AND the oracle on identical inputs at every hot-path call and carries the DEVICE result
+    forward.  A divergence of two free-running solves says nothing about where it started; here every call is compared on
+    the same operands, so the first discrepancy in status / iteration count / active set is pinned to one call, together
+    with the device's tie log for it (such a discrepancy must be a logged tie)."""
+
+    def __init__(self, dev_ops, relnorm_tol=1e-6):
+        self.dev = dev_ops
+        self.cpu = R.NumpyOps()
+        self.events = []          # discrepancies: dicts
+        self.calls = 0
+        self.minor = 0
+        self.worst = {}           # op -> largest relative deviation seen
+        self.min_margin = (np.inf, None)
+        self.tol = relnorm_tol
+
+    def _rel(self, op, a, b):
+        a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+        with np.errstate(all="ignore"):
+            d = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+        if not np.isfinite(d):
+            d = 0.0 if np.array_equal(a, b, equal_nan=True) else np.inf
+        self.worst[op] = max(self.worst.get(op, 0.0), d)
+        return d
+
+    def new_hessian(self, J, C, mu):
+        return (self.dev.new_hessian(J, C, mu), self.cpu.new_hessian(J, C, mu))
+
+    def hmul(self, H, v):
+        out = self.dev.hmul(H[0], v)
+        self._rel("hmul", out, self.cpu.hmul(H[1], v))
+        return out
+
+    def hmul_add(self, H, s, g):
+        out = self.dev.hmul_add(H[0], s, g)
+        self._rel("hmul_add", out, self.cpu.hmul(H[1], s) + g)
+        return out
+
+    def vthv(self, H, v):
+        out = self.dev.vthv(H[0], v)
+        self._rel("vthv", [out], [self.cpu.vthv(H[1], v)])
+        return out
+
+    def projection(self, lincons, r):
+        out = self.dev.projection(lincons, r)
+        self._rel("projection", out, self.cpu.projection(lincons, r))
+        return out
+
+    def minor_iterate(self, x, s, g_model, H, lincons, delta, kappa2):
+        self.minor += 1
+        w, st = self.dev.minor_iterate(x, s, g_model, H[0], lincons, delta, kappa2)
+        it_dev, ties = self.dev.last_iters, getattr(self.dev, "last_ties", None)
+        # the oracle on the same operands (its own projected_cg reports the iteration count)
+        w_l, w_u = R.build_step_bounds(x + s, lincons, delta)
+        w_o, st_o, it_o = R.projected_cg(g_model, H[1], w_l, w_u, lincons, kappa2)
+        if st_o != R.CGStatus.negative_curvature:
+            with np.errstate(all="ignore"):
+                w_o = R.linesearch(g_model, H[1], w_o, w_l, w_u, lincons.fixvars) * w_o
+        d = self._rel("minor_iterate", w, w_o)
+        if ties is not None and ties["min_margin"] < self.min_margin[0]:
+            self.min_margin = (ties["min_margin"], dict(ties, minor=self.minor))
+        if int(st) != int(st_o) or it_dev != it_o or d > self.tol:
+            self.events.append(dict(op="minor_iterate", minor=self.minor, status_dev=int(st), status_cpu=int(st_o), iters_dev=it_dev,
+                                    iters_cpu=it_o, rel=d, ties=ties))
+        return w, st
+
+    def cauchy_step(self, x, g, H, chol_aat_L, lincons, delta):
+        import copy
+        shadow = copy.copy(lincons)
+        shadow._dev = None
+        shadow.fixvars = lincons.fixvars.copy()
+        s = self.dev.cauchy_step(x, g, H[0], chol_aat_L, lincons, delta)
+        s_o = R.cauchy_step(x, g, H[1], chol_aat_L, shadow, delta, self.cpu)
+        d = self._rel("cauchy_step", s, s_o)
+        if not np.array_equal(shadow.fixvars, lincons.fixvars) or d > self.tol:
+            self.events.append(dict(op="cauchy_step", minor=self.minor, rel=d,
+                                    fix_dev=int(lincons.fixvars.sum()), fix_cpu=int(shadow.fixvars.sum())))
+        return s

@@ -1,11 +1,16 @@
-"""SURVEY.md §8(e) with the REAL library in two processes on one GPU.
+"""SURVEY.md §8(e) with the REAL library in several processes on one GPU.
 
-RCCL refuses two ranks on one device and the test box has one GPU, so the ranks' all-reduce goes through
-tests/multirank/staged_rccl.cpp (a host-staged stand-in bound via BH_RCCL_LIB; test infrastructure only).  Everything
-else is the product path: row shards uploaded per rank, C applied by rank 0 only, the launch-ahead CG / Cauchy schedules
-taking their decisions per rank.  The stand-in's barrier times out, so ranks whose launch schedules differ FAIL here
-instead of hanging.  Checked: both ranks hold bit-identical results, and those match the oracle on the unsharded problem.
+The test box has ONE GPU.  Two transports carry the ranks' all-reduce here:
+  * "ipc"    — the library's own one-shot peer-buffer exchange (BH_COMM=ipc): hipIpc handles work between processes on the
+               same device, so this is the product path end to end, no stand-in.
+  * "staged" — RCCL refuses two ranks on one device, so the library's RCCL call site is pointed (BH_RCCL_LIB) at
+               tests/multirank/staged_rccl.cpp, a host-staged stand-in for the five RCCL entry points (test infrastructure
+               only).  Its barrier times out, so ranks whose launch schedules differ FAIL here instead of hanging.
+Everything else is the product path: row shards uploaded per rank, C applied by rank 0 only, the launch-ahead CG / Cauchy
+schedules taking their decisions per rank.  Checked: all ranks hold bit-identical results, and those match the oracle on
+the unsharded problem.
 """
+import json
 import os
 import subprocess
 import sys
@@ -14,13 +19,44 @@ import uuid
 import numpy as np
 import pytest
 
-from _util import R, relnorm
+from _util import R, first_decision_difference, relnorm
 
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MR = os.path.join(HERE, "multirank")
 sys.path.insert(0, MR)
+
+
+def comm_env(comm):
+    env = dict(os.environ)
+    env.pop("BH_RCCL_LIB", None)
+    if comm == "ipc":
+        env["BH_COMM"] = "ipc"
+        return env, None
+    shm = "/bh_staged_%s" % uuid.uuid4().hex[:12]
+    env.update(BH_COMM="rccl", BH_RCCL_LIB=build_stand_in(), BH_STAGED_RCCL_SHM=shm)
+    return env, shm
+
+
+def run_ranks(script, world, tmp_path, comm, extra=(), timeout=420):
+    env, shm = comm_env(comm)
+    procs = [subprocess.Popen([sys.executable, os.path.join(MR, script), str(r), str(world), str(tmp_path)] + list(extra), env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=timeout)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        if shm:
+            try:
+                os.unlink("/dev/shm" + shm)
+            except OSError:
+                pass
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    return outs
 
 
 def build_stand_in():
@@ -32,26 +68,10 @@ def build_stand_in():
     return so
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_sharded_library_in_separate_processes(tmp_path, world):
+@pytest.mark.parametrize("comm,world", [("ipc", 2), ("ipc", 3), ("staged", 2)])
+def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     from problem import make_problem
-    so = build_stand_in()
-    shm = "/bh_staged_%s" % uuid.uuid4().hex[:12]
-    env = dict(os.environ, BH_RCCL_LIB=so, BH_STAGED_RCCL_SHM=shm)
-    procs = [subprocess.Popen([sys.executable, os.path.join(MR, "worker.py"), str(r), str(world), str(tmp_path)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
-    try:
-        outs = [p.communicate(timeout=420)[0] for p in procs]
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        try:
-            os.unlink("/dev/shm" + shm)
-        except OSError:
-            pass
-    for r, (p, o) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    run_ranks("worker.py", world, tmp_path, comm)
     res = [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
     # replicated state is bit-identical on every rank, and every rank issued the same number of all-reduces
@@ -114,3 +134,61 @@ def test_row_sharded_library_in_separate_processes(tmp_path, world):
     assert np.array_equal(z["cauchy_fix"], cau.fixvars)
     assert np.linalg.norm(z["cauchy_s"] - s_ref) <= 1e-9 * np.linalg.norm(s_ref)
     assert int(z["n_allreduce"]) >= int(z["box_tight_nh"]) + int(z["cauchy_nh"])
+
+
+@pytest.mark.parametrize("name,world", [("sphere", 2), ("sphere", 3), ("nls48", 2), ("nls48", 3)])
+def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name, world):
+    """the documented multi-GPU flow end to end.  The restated outer iteration runs replicated in `world`
+    processes whose residual / Jacobian callbacks return only their own rows; mx, g and the least-squares multipliers come from
+    the all-reduced entry points (bh_resid_sqnorm, bh_grad, bh_jtv), every hot-path call from the library, the exchange over
+    the peer-buffer path.  Ranks must agree bit for bit (replicated control flow); against the UNSHARDED oracle solve every
+    driver decision — CG exit status and active-set size of every minor iterate, every trust-region accept/resize — must be
+    identical up to the first decision whose deciding scalar is rounding noise in the reference's own arithmetic
+    (rho = ared/pred with |ared| worth a few ulps of mx, src/basic_tralcnlss.jl:353-354), and the solutions must agree."""
+    import solve_worker
+    run_ranks("solve_worker.py", world, tmp_path, "ipc", extra=[name])
+    xs = [np.load(os.path.join(tmp_path, "solve_%s_rank%d.npz" % (name, r))) for r in range(world)]
+    js = [json.load(open(os.path.join(tmp_path, "solve_%s_rank%d.json" % (name, r)))) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(xs[0]["x"], xs[r]["x"]) and np.array_equal(xs[0]["y"], xs[r]["y"]), "rank %d left the replicated trajectory" % r
+        assert js[0]["log"] == js[r]["log"], "rank %d took different driver decisions" % r
+    P = solve_worker.problem(name)
+    log_ref = []
+    x_ref, y_ref = R.tralcnllss(P["x0"], P["r"], P["jac_r"], P["c"], P["jac_c"], P["A"], P["b"], P["x_l"], P["x_u"], log=log_ref, **P["kw"])
+    log = [tuple(e) for e in js[0]["log"]]
+    diff = first_decision_difference(log_ref, log)
+    n_minor = sum(e[0] == "minor" for e in log)
+    with capsys.disabled():
+        print("[sharded solve %s x%d] %d minor iterates (oracle %d), %.1f s per rank, |x - x_oracle| = %.2e, first decision difference: %s"
+              % (name, world, n_minor, sum(e[0] == "minor" for e in log_ref), js[0]["seconds"], np.linalg.norm(xs[0]["x"] - x_ref),
+                 "none" if diff is None else "log entry %d: %s" % (diff[0], diff[3])))
+    if diff is None:
+        assert len(log) == len(log_ref)
+    else:
+        assert_rounding_dominated(diff)
+    assert np.linalg.norm(xs[0]["x"] - x_ref) <= 1e-4 * np.linalg.norm(x_ref)
+    assert np.linalg.norm(P["c"](xs[0]["x"])) < 1e-6 and np.linalg.norm(P["A"] @ xs[0]["x"] - P["b"]) < 1e-10
+
+
+def assert_rounding_dominated(diff):
+    """The first differing decision of two driver logs must be one the reference's own arithmetic cannot decide: a
+    trust-region ratio whose numerator ared = mx_next - mx is worth no more than a few hundred ulps of mx."""
+    k, a, b, why = diff
+    assert why, (k, a, b)
+    for name, va, vb, extra in why:
+        assert name.startswith("rho vs"), "driver decision %r differs (oracle %r, device %r) at log entry %d" % (name, va, vb, k)
+        assert extra["ared_in_ulps_of_mx"] <= 512.0, (k, name, extra)
+
+
+def test_launch_schedule_is_rank_independent_at_a_batch_threshold(tmp_path):
+    """shards of 21363 / 21362 / 21362 rows at n = 4096 put rank 0's own streaming-time estimate above the 100 us
+    launch-ahead threshold and the others' below it.  Over the RCCL call site (the stand-in fails on unmatched collectives)
+    every rank must enqueue the same iterations and all-reduces."""
+    world = 3
+    run_ranks("threshold_worker.py", world, tmp_path, "staged")
+    res = [np.load(os.path.join(tmp_path, "thr_rank%d.npz" % r)) for r in range(world)]
+    assert all(bool(z["same"]) for z in res)
+    for r in range(1, world):
+        assert np.array_equal(res[0]["w"], res[r]["w"]) and int(res[0]["n_allreduce"]) == int(res[r]["n_allreduce"])
+        assert int(res[0]["iters"]) == int(res[r]["iters"]) and int(res[0]["status"]) == int(res[r]["status"])
+    assert int(res[0]["n_hmul"]) >= 10
