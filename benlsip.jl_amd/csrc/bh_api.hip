@@ -77,7 +77,12 @@ struct Ctx {
     int64_t opt_variant = 0;         // kernel geometry variant for the 2048-chunk (n<=4096) class
     int64_t opt_batch = 0;           // CG iterations launched ahead of the host's done-flag poll; 0 = by problem size (auto_batch)
     int64_t opt_chol_blocked = 1;    // mA > 64: blocked potrf/trsm/syrk chain (0: one-workgroup right-looking kernel)
-    int64_t opt_chol_downdate = 1;   // Cauchy search: rank-one downdate of the factor per breakpoint (0: downdate the Gram matrix and refactor)
+    // Cauchy search, per breakpoint: 0 = downdate the Gram matrix A_free A_free' and refactor it (O(mA^3), the default: its
+    // factor is as accurate as the reference's from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2),
+    // half the time at mA = 64; errors accumulate over the breakpoints — measured on the 48-parameter NLS: after 29 downdates
+    // a search direction P(-g) with ||g||/||P(-g)|| = 1.7e7 came out different enough to take one more breakpoint than
+    // the oracle, where the refactoring path agrees with it to 1e-9)
+    int64_t opt_chol_downdate = 0;
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches

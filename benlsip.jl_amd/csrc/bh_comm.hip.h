@@ -103,12 +103,15 @@ __global__ __launch_bounds__(256) void reduce_exchange_kernel(const double* __re
     // ---- push: thread (rl = peer, cl = chunk) stores this rank's chunk into peer rl's inbox -------------------------------
     const int64_t slot_stride = pa.cap;                                         // doubles per (parity, rank) slot
     const int64_t my_slot = ((int64_t)par * kMaxPeers + pa.rank) * slot_stride;
+    // The payload goes out WRITE-THROUGH (system-scope stores: nothing stays dirty in this XCD's L2, so no L2 write-back
+    // fence is needed); every storing wave waits until its stores have been acknowledged, the workgroup meets, and only then
+    // is the flag raised (cdna_hip_programming.md Guideline 16, form R1).
     if (rl < pa.nranks && valid) sys_store_f64x2(pa.slots[rl] + my_slot + 2 * (int64_t)c, acc);
-    __threadfence_system();            // every storing wave drains its stores (release) before the flag is raised
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (rl < pa.nranks && cl == 0) {
         unsigned long long* f = pa.flags[rl] + ((int64_t)par * kMaxPeers + pa.rank) * pa.nblk_cap + blockIdx.x;
-        __hip_atomic_store(f, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(f, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
     // ---- wait for block `blockIdx.x` of every rank, then sum in rank order --------------------------------------------------
@@ -123,8 +126,10 @@ __global__ __launch_bounds__(256) void reduce_exchange_kernel(const double* __re
                 break;
             }
         }
-        __threadfence_system();        // acquire: the peers' payload stores are visible after their flags
     }
+    // every load of the payload below is a system-scope load into registers (it bypasses this CU's L1 and the XCD's L2), so
+    // the flag needs no cache-invalidating acquire behind it; the barrier orders the other waves' loads after the poll
+    asm volatile("" ::: "memory");
     __syncthreads();
     double2 got = make_double2(0.0, 0.0);
     if (rl < pa.nranks && valid)
@@ -141,7 +146,6 @@ __global__ __launch_bounds__(256) void reduce_exchange_kernel(const double* __re
     // ---- the last workgroup to finish advances the exchange counter ---------------------------------------------------------
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
         const unsigned done = atomicAdd(pa.arrive, 1u) + 1u;
         if (done == gridDim.x) {
             *pa.arrive = 0u;

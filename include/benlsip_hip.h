@@ -208,7 +208,7 @@ int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const doubl
                       double* alpha_out);
 /* cauchy_step(x, g, H, chol_aat, lincons, delta) — src/basic_tralcnlss.jl:574-639 (with next_breakpoint :536-562 and the
  * initial active_bounds!, src/polyhedral_constraints.jl:203-215), device-resident ("next" row f-3).  Per breakpoint: one
- * H*d, one projection, and a rank-one downdate + mA x mA Cholesky on the device in place of the reference's O(p^3)
+ * H*d, one projection, and a rank-one Gram downdate + mA x mA Cholesky on the device in place of the reference's O(p^3)
  * add_active! -> cholesky_aug_aat rebuild.  Needs the reduced projection form (default).  On return the handle holds the
  * final active set; fix_chunks_out (ceil(n/64) words, optional) receives it in BitVector.chunks layout so the caller can
  * update lincons.fixvars (and its own factor, if it still needs one). */
@@ -241,7 +241,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "pcg_batch"      [0] CG iterations enqueued per launch-ahead batch; 0 = by problem size (1 when an H*p streams >= 100 us)
  *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
- *   "chol_downdate"  [1] bh_cauchy_step: rank-one downdate of the factor per breakpoint (0: downdate the Gram matrix, refactor)
+ *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
+ *                        from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2), faster, errors accumulate)
  *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)
  *   "gram_mfma"      [1] A_free A_free' on fp64 MFMA when mA > 96 (2: always, 0: never)
  *   "rs_variant"     [0] A/B geometries of the row-streaming kernel for 2048 < n <= 4096 (tools/kernel_ab.py)

@@ -43,7 +43,10 @@ function handle(H::BEnlsip.AlHessian{Float64})
                     (Ref{Ptr{Cvoid}}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Int64, Int64, Float64),
                     ref, H.J, d, n, max(stride(H.J, 2), 1), H.C, q, max(stride(H.C, 2), 1), H.mu), "bh_hess_create")
         hh = HessHandle(ref[])
-        finalizer(x -> ccall((:bh_hess_destroy, libbh), Int32, (Ptr{Cvoid},), x.ptr), hh)
+        finalizer(hh) do x                     # idempotent: least_squares_multipliers finalizes its throw-away image early
+            x.ptr == C_NULL || ccall((:bh_hess_destroy, libbh), Int32, (Ptr{Cvoid},), x.ptr)
+            x.ptr = C_NULL
+        end
         hh
     end
     check(ccall((:bh_hess_set_mu, libbh), Int32, (Ptr{Cvoid}, Float64), h.ptr, H.mu), "bh_hess_set_mu")
@@ -174,8 +177,91 @@ function BEnlsip.update_chol!(lincons::BEnlsip.MixedConstraints{Float64}, chol_a
 end
 
 # ---- multi-GPU: one Julia process per GPU (e.g. MPI.jl / Distributed); rows of J and of r are sharded by the caller ----
+# ENV["BH_COMM"] = "rccl" (default) | "ipc" (one-shot peer-buffer exchange, ranks of one node) | "both" before comm_init.
 unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:bh_comm_unique_id, libbh), Int32, (Ptr{UInt8},), id), "bh_comm_unique_id"); id)
 comm_init(rank::Integer, nranks::Integer, id::Vector{UInt8}) =
     check(ccall((:bh_comm_init, libbh), Int32, (Int32, Int32, Ptr{UInt8}), rank, nranks, id), "bh_comm_init")
+comm_destroy() = check(ccall((:bh_comm_destroy, libbh), Int32, ()), "bh_comm_destroy")
+
+# Under row sharding `residuals(x)` / `jac_res(x)` return THIS rank's rows.  Everything the driver computes from them with
+# plain Matrix / Vector operations would then be a per-rank partial and the replicated control flow (rho = ared/pred,
+# initial_tr(g), the multipliers) would diverge between ranks.  The reference touches residual rows directly in exactly
+# four places; each gets a Float64 method that routes the row-dependent part through an all-reduced entry point
+# (with one rank they compute the same values, on the device):
+#     new_point                  src/basic_tralcnlss.jl:32-49   mx (:44) and g (:45)
+#     evaluate_al                :51-61                         mx (:58)
+#     first_derivatives          :63-77                         g (:74)
+#     least_squares_multipliers  :887-903                       g = jac_res(x)' * residuals(x) (:893)
+# (tralcnllss's own uses of rx — size(rx,1) and dot(rx,rx) at :214,:239,:291 — only feed the log.)
+# These four are exercised, through the same C entry points, by tests/test_multirank_gpu.py::
+# test_whole_row_sharded_solve_matches_unsharded_oracle (tests/hip_ops.py::ShardedHipOps is their executable mirror).
+
+"dot(rx,rx) over ALL ranks' rows — bh_resid_sqnorm."
+function resid_sqnorm(rx::Vector{Float64})
+    out = Ref{Float64}(0.0)
+    check(ccall((:bh_resid_sqnorm, libbh), Int32, (Ptr{Float64}, Int64, Ref{Float64}), rx, length(rx), out), "bh_resid_sqnorm")
+    return out[]
+end
+
+"g = Jx'*rx + Cx'*y_bar with the J' product summed over all ranks (C'y_bar is added by rank 0) — bh_grad."
+function gradient(H::BEnlsip.AlHessian{Float64}, rx::Vector{Float64}, y_bar::Vector{Float64})
+    g = Vector{Float64}(undef, size(H.J, 2))
+    check(ccall((:bh_grad, libbh), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), handle(H), rx, y_bar, g), "bh_grad")
+    return g
+end
+
+function BEnlsip.new_point(x::Vector{Float64}, y::Vector{Float64}, mu::Float64, residuals::F1, nlconstraints::F2,
+                           jac_res::F3, jac_nlcons::F4) where {F1<:Function, F2<:Function, F3<:Function, F4<:Function}
+    rx, cx = residuals(x), nlconstraints(x)
+    Jx, Cx = jac_res(x), jac_nlcons(x)
+    y_bar = y + mu*cx
+    mx = 0.5*resid_sqnorm(rx) + dot(y,cx) + 0.5*mu*dot(cx,cx)     # :44
+    H = BEnlsip.AlHessian(Jx,Cx,mu)                                # :46 (first, so that g can use its device image)
+    g = gradient(H, rx, y_bar)                                     # :45
+    return rx, cx, y_bar, mx, g, H
+end
+
+function BEnlsip.evaluate_al(x::Vector{Float64}, y::Vector{Float64}, mu::Float64, residuals::F1,
+                             nlconstraints::F2) where {F1<:Function, F2<:Function}
+    rx, cx = residuals(x), nlconstraints(x)
+    mx = 0.5*resid_sqnorm(rx) + dot(y,cx) + 0.5*mu*dot(cx,cx)     # :58
+    return rx, cx, mx
+end
+
+# first_derivatives returns (y_bar, Jx, Cx, g) and the caller builds the AlHessian from Jx, Cx afterwards (:361-362).  The
+# handle made here for g is keyed on ITS AlHessian object, so the caller's new object uploads J a second time; to avoid
+# that, the AlHessian built here is remembered and handed to the next second_derivatives call with the same matrices.
+const PENDING_HESS = Ref{Union{Nothing,BEnlsip.AlHessian{Float64}}}(nothing)
+
+function BEnlsip.first_derivatives(x::Vector{Float64}, y::Vector{Float64}, mu::Float64, rx::Vector{Float64}, cx::Vector{Float64},
+                                   jac_res::F1, jac_nlcons::F2) where {F1<:Function, F2<:Function}
+    Jx, Cx = jac_res(x), jac_nlcons(x)
+    y_bar = y + mu*cx
+    H = BEnlsip.AlHessian(Jx,Cx,mu)
+    g = gradient(H, rx, y_bar)                                     # :74
+    PENDING_HESS[] = H
+    return y_bar, Jx, Cx, g
+end
+
+function BEnlsip.second_derivatives(Jx::Matrix{Float64}, Cx::Matrix{Float64}, mu::Float64)
+    H = PENDING_HESS[]
+    PENDING_HESS[] = nothing
+    (H !== nothing && H.J === Jx && H.C === Cx && H.mu == mu) && return H     # the object whose image is already in HBM
+    return BEnlsip.AlHessian(Jx,Cx,mu)                                        # :84
+end
+
+function BEnlsip.least_squares_multipliers(x::Vector{Float64}, residuals::F1, jac_res::F2,
+                                           jac_nlcons::F3) where {F1<:Function, F2<:Function, F3<:Function}
+    Jx = jac_res(x)
+    H = BEnlsip.AlHessian(Jx, zeros(0, size(Jx, 2)), 0.0)          # a throw-away image: J'r once per solve
+    g = gradient(H, residuals(x), Float64[])                       # :893, summed over ranks
+    finalize(HESS[H])
+    delete!(HESS, H)
+    C = jac_nlcons(x)
+    chol_cct = cholesky(C*C')
+    b = -C*g
+    v = chol_cct.L \ b
+    return chol_cct.U \ v
+end
 
 end # module

@@ -50,8 +50,10 @@ def main():
         out["sphere_" + cls.__name__] = dict(opt=opt(xs, ys), minor=sum(e[0] == "minor" for e in log), same_log_len=len(log) == len(log_ref))
     sh = ShadowOps(HipOpsDeviceAll(bh))
     xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, ops=sh, **kw)
-    print("[sphere] shadow solve: %d minor iterates, %d same-operand discrepancies %s; worst relative deviations %s; closest margin %s"
-          % (sh.minor, len(sh.events), sh.events[:3], {k: "%.1e" % v for k, v in sh.worst.items()}, sh.min_margin))
+    print("[sphere] shadow solve: %d minor iterates, %d same-operand discrepancies; worst relative deviations %s; closest margin %s"
+          % (sh.minor, len(sh.events), {k: "%.1e" % v for k, v in sh.worst.items()}, sh.min_margin))
+    for e in sh.events[:30]:
+        print("        ", {k: v for k, v in e.items() if k != "operands"})
 
     # ---- 48-parameter NLS ----------------------------------------------------------------------------------------------
     P = NLSProblem(256, 48, 2, seed=1)
@@ -81,8 +83,32 @@ def main():
     x, y = R.tralcnllss(P.x0, P.r, P.jac_r, P.c, P.jac_c, P.A, P.b, P.x_l, P.x_u, ops=sh, **kw)
     print("[nls48] shadow solve: %d minor iterates, %d same-operand discrepancies; worst relative deviations %s; closest margin %s"
           % (sh.minor, len(sh.events), {k: "%.1e" % v for k, v in sh.worst.items()}, sh.min_margin))
-    for e in sh.events[:10]:
-        print("        ", e)
+    for e in sh.events[:40]:
+        print("        ", {k: v for k, v in e.items() if k != "operands"})
+    cau = [e for e in sh.events if e["op"] == "cauchy_step"]
+    if cau:
+        worst = max(cau, key=lambda e: e["rel"] / max(e["oracle_sensitivity"], 1e-300))
+        print("[nls48] worst Cauchy event relative to the oracle's own sensitivity:", {k: v for k, v in worst.items() if k != "operands"})
+        op = worst["operands"]
+        np.savez(os.path.join(ROOT, "gpurun_out", "cauchy_worst.npz"), A=P.A, x_l=P.x_l, x_u=P.x_u, **op)
+        # the same operands through the device variants
+        A = P.A
+        L0 = R.chol_lower(A @ A.T)
+        Ho = R.AlHessian(op["J"], op["C"], float(op["mu"]))
+        Hd = bh.AlHessian(op["J"], op["C"], float(op["mu"]))
+        for dd in (1, 0):
+            bh.set_option("chol_downdate", dd)
+            cons = bh.MixedConstraints(A, None, op["fix0"], l=P.x_l, u=P.x_u)
+            sd, info = bh.cauchy_step(op["x"], op["g"], Hd, cons, float(op["delta"]), full_output=True)
+            print("        device, chol_downdate=%d: %d breakpoints, |s - s_cpu|/|s_cpu| = %.2e, |s - s_dev(solve)|/|s| = %.2e"
+                  % (dd, info["n_breakpoints"], np.linalg.norm(sd - op["s_cpu"]) / np.linalg.norm(op["s_cpu"]), np.linalg.norm(sd - op["s_dev"]) / np.linalg.norm(op["s_dev"])))
+        bh.set_option("chol_downdate", 1)
+        # the oracle in extended precision for the projections' inner products: where is the truth?
+        lc = R.make_mixed_constraints(A, L0, l=P.x_l, u=P.x_u)
+        R.active_bounds_inplace(lc, op["x"], L0)
+        d0 = R.projection(lc, -op["g"])
+        dd0 = bh.projection(bh.MixedConstraints(A, None, lc.fixvars, l=P.x_l, u=P.x_u), -op["g"])
+        print("        initial direction d = P(-g): |g| = %.3e, |d_cpu| = %.3e, |d_dev - d_cpu| = %.3e" % (np.linalg.norm(op["g"]), np.linalg.norm(d0), np.linalg.norm(dd0 - d0)))
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "divergence_probe.json"), "w"), indent=1) if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None
 
 

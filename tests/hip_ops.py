@@ -142,7 +142,14 @@ class ShadowOps:
 
     def projection(self, lincons, r):
         out = self.dev.projection(lincons, r)
-        self._rel("projection", out, self.cpu.projection(lincons, r))
+        ref = self.cpu.projection(lincons, r)
+        # a projection is a difference r - A~'(...): its error scales with ||r||, not with the (possibly tiny) result
+        with np.errstate(all="ignore"):
+            d = float(np.linalg.norm(out - ref) / max(np.linalg.norm(r), 1e-300))
+        self.worst["projection"] = max(self.worst.get("projection", 0.0), d)
+        if d > 1e-10:
+            self.events.append(dict(op="projection", minor=self.minor, rel=d, nfix=int(lincons.fixvars.sum()),
+                                    shrink=float(np.linalg.norm(ref) / max(np.linalg.norm(r), 1e-300))))
         return out
 
     def minor_iterate(self, x, s, g_model, H, lincons, delta, kappa2):
@@ -159,8 +166,17 @@ class ShadowOps:
         if ties is not None and ties["min_margin"] < self.min_margin[0]:
             self.min_margin = (ties["min_margin"], dict(ties, minor=self.minor))
         if int(st) != int(st_o) or it_dev != it_o or d > self.tol:
+            rng = np.random.default_rng(self.minor)
+            sens = 0.0
+            for _ in range(3):           # the oracle's own w under last-bit perturbations of its right-hand side
+                g2 = g_model * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, g_model.shape[0]))
+                w2, st2, _ = R.projected_cg(g2, H[1], w_l, w_u, lincons, kappa2)
+                if st2 != R.CGStatus.negative_curvature:
+                    with np.errstate(all="ignore"):
+                        w2 = R.linesearch(g2, H[1], w2, w_l, w_u, lincons.fixvars) * w2
+                sens = max(sens, float(np.linalg.norm(w2 - w_o) / max(np.linalg.norm(w_o), 1e-300)))
             self.events.append(dict(op="minor_iterate", minor=self.minor, status_dev=int(st), status_cpu=int(st_o), iters_dev=it_dev,
-                                    iters_cpu=it_o, rel=d, ties=ties))
+                                    iters_cpu=it_o, rel=d, oracle_sensitivity=sens, ties=ties))
         return w, st
 
     def cauchy_step(self, x, g, H, chol_aat_L, lincons, delta):
@@ -168,10 +184,28 @@ class ShadowOps:
         shadow = copy.copy(lincons)
         shadow._dev = None
         shadow.fixvars = lincons.fixvars.copy()
+        fix0, chol0 = lincons.fixvars.copy(), lincons.chol_L
         s = self.dev.cauchy_step(x, g, H[0], chol_aat_L, lincons, delta)
         s_o = R.cauchy_step(x, g, H[1], chol_aat_L, shadow, delta, self.cpu)
         d = self._rel("cauchy_step", s, s_o)
         if not np.array_equal(shadow.fixvars, lincons.fixvars) or d > self.tol:
-            self.events.append(dict(op="cauchy_step", minor=self.minor, rel=d,
-                                    fix_dev=int(lincons.fixvars.sum()), fix_cpu=int(shadow.fixvars.sum())))
+            # how far does the ORACLE's own Cauchy step move when g is perturbed in its last bits?  (the search direction is
+            # P(-g), a cancelling difference once g is nearly orthogonal to the null space: near a critical point its
+            # relative accuracy is eps*||g||/||P(-g)||, whoever computes it)
+            rng = np.random.default_rng(self.minor)
+            sens = 0.0
+            for _ in range(3):
+                sh2 = copy.copy(lincons)
+                sh2._dev = None
+                sh2.fixvars = fix0.copy()
+                sh2.chol_L = chol0
+                g2 = g * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, g.shape[0]))
+                s2 = R.cauchy_step(x, g2, H[1], chol_aat_L, sh2, delta, self.cpu)
+                sens = max(sens, float(np.linalg.norm(s2 - s_o) / max(np.linalg.norm(s_o), 1e-300)))
+            red = self.cpu.projection(shadow, -g)
+            self.events.append(dict(op="cauchy_step", minor=self.minor, rel=d, oracle_sensitivity=sens,
+                                    fix_dev=int(lincons.fixvars.sum()), fix_cpu=int(shadow.fixvars.sum()),
+                                    g_over_reduced_g=float(np.linalg.norm(g) / max(np.linalg.norm(red), 1e-300)),
+                                    operands=dict(x=x.copy(), g=g.copy(), delta=delta, fix0=fix0.copy(), J=H[1].J.copy(), C=H[1].C.copy(), mu=H[1].mu,
+                                                  s_dev=s.copy(), s_cpu=s_o.copy())))
         return s
