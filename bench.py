@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — PCG subproblems/s + achieved HBM GB/s of the dominant kernel, BASELINE config 3 per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A step = one complete projected_cg subproblem (bh_pcg_dev: initial projection -> CG loop -> status) on the synthetic
-dense NLS instance of SURVEY.md §8(d): J is (N*65536) x 4096 fp64, rows sharded 65536 per GPU (J generated in HBM), box
-bounds with p = 512 active, mu = 10, kappa2 = 0.1; all vectors are resident in HBM when the timed region starts.
-Weak scaling: each rank always owns a 65536 x 4096 shard (2 GiB); with N > 1 every H*p ends in one RCCL all-reduce of
-n doubles.  `value` counts one unit per rank-shard per subproblem (N units per step), so it is the whole-job aggregate.
+dense NLS instance of SURVEY.md §8(d): box bounds with p = 512 active, mu = 10, kappa2 = 0.1; all vectors are resident in
+HBM when the timed region starts.
+  weak scaling (default): J is (N*65536) x 4096 fp64, every rank owns a 65536 x 4096 shard (2 GiB, generated in HBM);
+  strong scaling: J is 65536 x 4096 whatever N is, rows split over the ranks (SURVEY.md §8e's "visible all-reduce" case).
+With N > 1 every H*p ends in one all-reduce of n doubles.  `value` = subproblems per second of the WHOLE JOB (all ranks work
+on the same subproblem: it is counted once); `shard_units_per_s` = N x that (one unit per 65536-row shard, weak scaling only).
 """
 import argparse
 import json
@@ -49,9 +51,9 @@ def cpu_share():
         return os.cpu_count() or 1
 
 
-def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS):
+def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS, strong=False):
     syn = bh.synthetic
-    d_total = d_per_gpu * world
+    d_total = d_per_gpu if strong else d_per_gpu * world
     lo, hi = bh.row_shard(d_total, rank, world)
     H = bh.AlHessian.synthetic(hi - lo, n, row0=lo, d_total=d_total, seed=1, colscale=syn.column_scale(n, kind), mu=10.0)
     x, x_l, x_u, fix = syn.box_vectors(n, fix_every=8)
@@ -84,43 +86,52 @@ def run_steps(bh, H, cons, dv, kappa2, steps):
     return out
 
 
-def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, d_sample=16384):
-    """The oracle timed on a bounded sample of the same workload: rows [0, d_sample) of the same J (same vectors recipe),
-    full projected_cg calls, scaled to the full row count and to the GPU run's H*p count.  Two ports are timed: the
-    plain-C/OpenMP restatement (oracle/benlsip_oracle.c, all host cores) and the NumPy/OpenBLAS one (the dgemv family
-    Julia's LinearAlgebra dispatches to); `value` is the faster of the two."""
+def host_synthetic_J(R, d, n, kind, chunk=8192):
+    """The same J the device generates (counter-based), built on the host in row blocks (Fortran order)."""
+    J = np.empty((d, n), order="F")
+    for lo in range(0, d, chunk):
+        hi = min(d, lo + chunk)
+        J[lo:hi] = R.synthetic_J(hi - lo, n, seed=1, kind=kind, row0=lo, d_total=d)
+    return J
+
+
+def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, repeats=5):
+    """The oracle timed on the host cores, on the FULL bench workload (the same 65536 x 4096 J, 2 GiB, same vectors recipe):
+    whole projected_cg calls, >= `repeats` of them per port, median.  Two ports are timed: the plain-C/OpenMP restatement
+    (oracle/benlsip_oracle.c) and the NumPy/OpenBLAS one (the dgemv family Julia's LinearAlgebra dispatches to); `value` is
+    the faster of the two.  Bounded: ~2 H*p of ~12-25 ms per call, a handful of calls per port and team size."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import benlsip_oracle as BO
     import benlsip_ref as R
-    J = R.synthetic_J(d_sample, n, seed=1, kind=kind, d_total=d_full)
-    inst = R.synthetic_box_vectors(d_sample, n, fix_every=8)
+    t_gen = time.perf_counter()
+    J = host_synthetic_J(R, d_full, n, kind)
+    t_gen = time.perf_counter() - t_gen
+    inst = R.synthetic_box_vectors(d_full, n, fix_every=8)
     A = np.zeros((0, n))
     Z = np.zeros((0, n))
     cons = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
     g = J.T @ inst.r0
     w_l, w_u = R.build_step_bounds(inst.x, cons, R.initial_tr(g))
 
-    def timed(fn, budget):
-        n_h = fn()                                   # warm-up, returns the H*p count on the sample
-        reps, t0 = 0, time.perf_counter()
-        while True:
+    def timed(fn):
+        n_h = fn()                                   # warm-up, returns the H*p count of one subproblem
+        ts = []
+        for _ in range(repeats):
+            t0 = time.perf_counter()
             fn()
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > budget or reps >= 50:
-                break
-        return el / reps / max(n_h, 1), reps
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), n_h
 
-    # the C/OpenMP port at several team sizes (a 128-thread team is not the fastest for a memory-bound dgemv), best kept
+    # the C/OpenMP port at a few team sizes (a 128-thread team is not the fastest for a memory-bound dgemv), best kept
     omp_max = BO.num_threads()
-    t_c, reps_c, omp_best, by_team = None, 0, omp_max, {}
     share = cpu_share()
-    for team in sorted({t for t in (8, 16, 32, 64, share, omp_max) if t <= omp_max}):
+    t_c, omp_best, by_team, nh_c = None, omp_max, {}, 0
+    for team in sorted({t for t in (8, 32, share, omp_max) if t <= omp_max}):
         BO.set_num_threads(team)
-        t_k, reps_k = timed(lambda: BO.projected_cg(g, J, Z, 10.0, w_l, w_u, A, inst.fixvars, cons.chol_L, kappa2)[3], 2.5)
-        by_team[team] = 1e3 * t_k * (d_full / d_sample)
+        t_k, nh_c = timed(lambda: BO.projected_cg(g, J, Z, 10.0, w_l, w_u, A, inst.fixvars, cons.chol_L, kappa2)[3])
+        by_team[team] = 1e3 * t_k / max(nh_c, 1)
         if t_c is None or t_k < t_c:
-            t_c, reps_c, omp_best = t_k, reps_k, team
+            t_c, omp_best = t_k, team
     BO.set_num_threads(omp_max)
     H = R.AlHessian(J, Z, 10.0)
 
@@ -128,29 +139,29 @@ def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, d_sample=
         tr = R.CGTrace()
         R.projected_cg(g, H, w_l, w_u, cons, kappa2, trace=tr)
         return tr.n_hmul
-    t_np, reps_np = timed(np_run, 3.0)
+    t_np, nh_np = timed(np_run)
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
         np_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-        # the box exposes more hardware threads than its CPU share: OpenBLAS at the C port's best team size as well
-        with threadpool_limits(limits=int(omp_best)):
-            t_np2, reps_np2 = timed(np_run, 3.0)
-        if t_np2 < t_np:
-            t_np, reps_np, np_threads = t_np2, reps_np2, int(omp_best)
+        if int(omp_best) != np_threads:
+            # the box exposes more hardware threads than its CPU share: OpenBLAS at the C port's best team size as well
+            with threadpool_limits(limits=int(omp_best)):
+                t_np2, _ = timed(np_run)
+            if t_np2 < t_np:
+                t_np, np_threads = t_np2, int(omp_best)
     except Exception:
         np_threads = os.cpu_count() or 1
-    scale = d_full / d_sample
-    best, cores, which = (t_c, omp_best, "C/OpenMP") if t_c <= t_np else (t_np, np_threads, "NumPy/OpenBLAS")
-    t_full = best * scale * max(n_hmul_gpu, 1)
+    best, cores, which, nh = (t_c, omp_best, "C/OpenMP", nh_c) if t_c <= t_np else (t_np, np_threads, "NumPy/OpenBLAS", nh_np)
     return {
-        "value": 1.0 / t_full, "unit": "PCG subproblems/s", "cores": int(cores), "kind": "port",
-        "sample": "oracle projected_cg on rows [0,%d) of the same %dx%d J (1/%d of the rows; %s port, %d repeats); time per H*p "
-                  "scaled x%d in rows and to the GPU run's %d H*p per subproblem"
-                  % (d_sample, d_full, n, d_full // d_sample, which, reps_c if which == "C/OpenMP" else reps_np, d_full // d_sample, n_hmul_gpu),
-        "ms_per_hmul_full_size": {"c_openmp": 1e3 * t_c * scale, "numpy_openblas": 1e3 * t_np * scale},
+        "value": 1.0 / best, "unit": "PCG subproblems/s", "cores": int(cores), "kind": "port",
+        "sample": "oracle projected_cg (%s port) on the FULL workload: the same %d x %d J (2 GiB, host copy of the device generator), "
+                  "%d H*p per subproblem (GPU run: %d), median of %d whole subproblems after one warm-up"
+                  % (which, d_full, n, nh, n_hmul_gpu, repeats),
+        "ms_per_subproblem": {"c_openmp": 1e3 * t_c, "numpy_openblas": 1e3 * t_np},
+        "ms_per_hmul": {"c_openmp": 1e3 * t_c / max(nh_c, 1), "numpy_openblas": 1e3 * t_np / max(nh_np, 1)},
         "threads": {"c_openmp": int(omp_best), "numpy_openblas": int(np_threads)},
         "c_openmp_ms_per_hmul_by_team": by_team, "cpu_share": share, "hardware_threads": os.cpu_count(),
-        "host_gbs": 2 * 8.0 * d_sample * n / best / 1e9,
+        "host_gbs": 2 * 8.0 * d_full * n * max(nh, 1) / best / 1e9, "host_J_generation_s": t_gen,
     }
 
 
@@ -159,6 +170,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 65536 rows per GPU (default); strong: the 65536 rows of config 3 split over the GPUs")
     ap.add_argument("--variant", choices=["wc", "ic"], default="wc",
                     help="wc: well-conditioned J (a handful of CG iterations); ic: columns scaled 10^(-3j/n) (hundreds)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -181,15 +194,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         args.gpus = world
+    strong = args.scaling == "strong"
 
     import torch
     dist = None
     # BH_BENCH_REHEARSAL=1: run the N > 1 code path on a ONE-GPU box — every rank on device 0, torch over gloo, the
-    # library's all-reduce through the host-staged stand-in (BH_RCCL_LIB, tests/multirank/) — to exercise this script's
-    # multi-rank flow (shards, replica check, teardown).  Its numbers mean nothing and are labelled as such.
+    # library's all-reduce over its peer-buffer transport (hipIpc works between processes on one device; RCCL refuses
+    # duplicate devices) — to exercise this script's multi-rank flow (shards, replica check, teardown).  Its numbers mean
+    # nothing and are labelled as such.
     rehearsal = os.environ.get("BH_BENCH_REHEARSAL", "0") not in ("", "0")
     if rehearsal:
         local_rank = 0
+        os.environ.setdefault("BH_COMM", "ipc")
     else:
         # a launcher that pins one visible device per rank (HIP_VISIBLE_DEVICES) leaves every rank with ordinal 0
         local_rank %= max(torch.cuda.device_count(), 1)
@@ -203,8 +219,25 @@ def main():
 
     import benlsip_jl_amd as bh
     bh.init(local_rank, flags=bh._lib.BH_FLAG_PROFILE)
-    if dist is not None:
-        bh.init_distributed(rank, world, bh.torch_broadcast_bytes(torch.device("cuda", local_rank)))
+    comm_note = None
+    if dist is not None and world > 1:
+        # RCCL carries the timed region (BASELINE's north_star names it); the library's one-shot peer-buffer exchange is
+        # brought up next to it when possible and measured afterwards, outside the timed region.
+        bcast = bh.torch_broadcast_bytes(None if rehearsal else torch.device("cuda", local_rank))
+        user_choice = "BH_COMM" in os.environ
+        os.environ.setdefault("BH_COMM", "both")
+        try:
+            bh.init_distributed(rank, world, bcast)
+        except bh.BenlsipHipError as e:
+            if user_choice:
+                raise
+            # the handle exchange fails on every rank or on none (shared flag + barriers): all ranks take this branch together
+            comm_note = "peer-buffer transport unavailable (%s); RCCL only" % e
+            os.environ["BH_COMM"] = "rccl"
+            bh.init_distributed(rank, world, bcast)
+    elif dist is not None:
+        bh.init_distributed(rank, world, bh.torch_broadcast_bytes(None if rehearsal else torch.device("cuda", local_rank)))
+    comm_mode = os.environ.get("BH_COMM", "rccl") if world > 1 else None
 
     def barrier():
         bh._lib.lib().bh_synchronize()
@@ -213,56 +246,68 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    tdev = "cpu" if rehearsal else "cuda"
+
+    def gather(values):
+        """Every rank's list of floats, as an (N, len) array on every rank."""
+        if dist is None or world == 1:
+            return np.asarray([values], dtype=np.float64)
+        t = torch.zeros(world, len(values), dtype=torch.float64, device=tdev)
+        t[rank] = torch.tensor(values, dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
     kind = 0 if args.variant == "wc" else 1
     kappa2 = 0.1
-    H, cons, dv, host = setup_instance(bh, rank, world, kind)
+    H, cons, dv, host = setup_instance(bh, rank, world, kind, strong=strong)
 
-    run_steps(bh, H, cons, dv, kappa2, args.warmup)
-    H.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    status, iters, n_hmul = run_steps(bh, H, cons, dv, kappa2, args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    st = H.stats()
+    def timed_run(steps, warmup):
+        run_steps(bh, H, cons, dv, kappa2, warmup)
+        H.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        out = run_steps(bh, H, cons, dv, kappa2, steps)
+        barrier()
+        el = time.perf_counter() - t0
+        return float(gather([el]).max()), out, H.stats()
+
+    # short runs: time EVERY H*p launch with hipEvents (an event pair costs ~10 us of stream time, so long runs sample every 8th)
+    st_probe = run_steps(bh, H, cons, dv, kappa2, 1)
+    bh.set_option("profile_stride", 1 if args.steps * st_probe[2] <= 64 else 8)
+    elapsed, (status, iters, n_hmul), st = timed_run(args.steps, args.warmup)
     replicas_identical = None
-    if dist is not None:
+    if dist is not None and world > 1:
         # Lock-step check (outside the timed region): w is replicated state, every rank must hold the SAME BITS — the
         # launch-ahead schedule relies on it (DESIGN.md §6).  Compare a checksum of the bit patterns across ranks.
         bits = dv["w"].download().view(np.int64)
-        chk = int(np.bitwise_xor.reduce(bits)) ^ (int(iters) << 20) ^ int(n_hmul)
-        lo_hi = torch.tensor([chk, -chk], dtype=torch.int64, device="cuda")
-        dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
-        replicas_identical = bool(int(lo_hi[0].item()) == chk and int(lo_hi[1].item()) == -chk)
-        flag = torch.tensor([1 if replicas_identical else 0], dtype=torch.int64, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        replicas_identical = bool(flag.item())
+        chk = float(int(np.bitwise_xor.reduce(bits)) % (1 << 52)) + float(iters) * 1e-3 + float(n_hmul) * 1e-6
+        allchk = gather([chk])
+        replicas_identical = bool(np.all(allchk == allchk[0]))
 
     traffic, traffic_src = pmc_traffic() if world == 1 else (None, None)
     ms_per_step = 1e3 * elapsed / args.steps
     hmul_ms = st["hmul_ms"] / max(st["hmul_timed"], 1)
     achieved = st["bytes_per_hmul"] / (hmul_ms * 1e-3) / 1e9 if hmul_ms > 0 else 0.0
+    per_rank = gather([achieved, hmul_ms, st["bytes_per_hmul"], float(host["hi"] - host["lo"])])
+    rows_per_gpu = host["d_total"] // world
     line = {
         "metric": "PCG subproblems/sec + achieved HBM GB/s, dense m=65536 n=4096 fp64",     # BASELINE.json's metric, verbatim
-        "value": world * args.steps / elapsed,
+        "value": args.steps / elapsed,
         "unit": "PCG subproblems/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on one GPU (all ranks share device 0, host-staged all-reduce): not a measurement",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on one GPU (all ranks share device 0): not a measurement",
         "config": {
-            "workload": "BASELINE config 3 per GPU: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), box bounds, "
+            "workload": "BASELINE config 3%s: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), box bounds, "
                         "p=512 active, mu=10, kappa2=0.1, variant=%s; one step = one projected_cg subproblem (bh_pcg_dev), "
-                        "vectors resident in HBM" % (host["d_total"], N_COLS, D_PER_GPU, args.variant),
-            "unit_definition": "one unit = one 65536x4096 row shard of one projected_cg call: at N GPUs a step solves ONE subproblem "
-                               "on N*65536 rows and counts N units (weak scaling); subproblems_per_s_global counts it once",
-            "d_total": host["d_total"], "n": N_COLS, "rows_per_gpu": D_PER_GPU, "parallelism": "row-shard x%d + 1 all-reduce(n) per H*p" % world,
+                        "vectors resident in HBM" % (" (rows split over the GPUs)" if strong else " per GPU", host["d_total"], N_COLS, rows_per_gpu, args.variant),
+            "unit_definition": "value counts one unit per projected_cg subproblem of the whole job (all ranks work on the same subproblem); "
+                               "under weak scaling the subproblem grows with N (N*65536 rows): shard_units_per_s = N * value",
+            "d_total": host["d_total"], "n": N_COLS, "rows_per_gpu": rows_per_gpu,
+            "parallelism": "row-shard x%d + 1 all-reduce(n) per H*p" % world,
             "cg_status": status.name, "cg_iters_per_subproblem": iters - 1, "hmul_per_subproblem": n_hmul,
         },
-        "subproblems_per_s_global": args.steps / elapsed,
+        "shard_units_per_s": (world * args.steps / elapsed) if not strong else None,
         "replicas_bitwise_identical": replicas_identical,
         "cg_iters_per_s": (iters - 1) * args.steps / elapsed,
         "ms_per_cg_iteration": ms_per_step / max(n_hmul, 1),
@@ -272,9 +317,35 @@ def main():
             "frac_of_guide_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": st["bytes_per_hmul"], "avg_launch_ms": hmul_ms,
-            "launches_timed": st["hmul_timed"],
+            "launches_timed": st["hmul_timed"], "rank": rank,
+            "achieved_min_over_ranks": float(per_rank[:, 0].min()), "achieved_max_over_ranks": float(per_rank[:, 0].max()),
+            "per_rank": [{"rank": r, "achieved": float(per_rank[r, 0]), "avg_launch_ms": float(per_rank[r, 1]),
+                          "algorithmic_bytes_per_launch": float(per_rank[r, 2]), "rows": int(per_rank[r, 3])} for r in range(world)],
         },
     }
+    if world > 1:
+        # what the exchange costs: back-to-back all-reduces of one n-vector on the library stream (all ranks together)
+        comm = {"mode": comm_mode, "timed_region_path": "rccl" if comm_mode in ("rccl", "both") else "peer_buffers", "note": comm_note}
+        try:
+            if comm_mode in ("rccl", "both"):
+                bh.set_option("comm_path", 0)
+                comm["rccl_allreduce_us"] = float(gather([1e3 * H.time_kernel(7, 200)]).max())
+                comm["rccl_reduce_plus_allreduce_us"] = float(gather([1e3 * H.time_kernel(8, 200)]).max())
+            if comm_mode in ("ipc", "both"):
+                bh.set_option("comm_path", 1)
+                comm["peer_allreduce_us"] = float(gather([1e3 * H.time_kernel(7, 200)]).max())
+                comm["peer_reduce_plus_allreduce_us"] = float(gather([1e3 * H.time_kernel(8, 200)]).max())
+                if comm_mode == "both":
+                    # the same subproblems with the exchange on the peer buffers (outside the headline's timed region)
+                    el_p, (st_p, it_p, nh_p), _ = timed_run(max(args.steps // 2, 1), 2)
+                    comm["peer_path_run"] = {"steps": max(args.steps // 2, 1), "ms_per_step": 1e3 * el_p / max(args.steps // 2, 1),
+                                             "value": max(args.steps // 2, 1) / el_p, "cg_status": st_p.name, "hmul_per_subproblem": nh_p}
+                    bh.set_option("comm_path", 0)
+        except bh.BenlsipHipError as e:
+            comm["error"] = str(e)
+        comm["allreduce_us"] = comm.get("rccl_allreduce_us", comm.get("peer_allreduce_us"))
+        line["comm"] = comm
+        line["allreduce_us"] = comm["allreduce_us"]
     if not args.no_extras:
         d_loc = host["hi"] - host["lo"]
         mv_bytes = 8.0 * d_loc * N_COLS + 8.0 * N_COLS + 8.0 * d_loc
@@ -295,6 +366,7 @@ def main():
             "ms_by_workgroups_per_cu": probe_ms,
             "note": "read_probe_kernel: 16-byte non-temporal loads + adds only, same J image; what a single-read kernel can reach here",
         }
+        line["post_stream_us"] = 1e3 * H.time_kernel(8, 200) if world == 1 else None    # slab reduction after the streaming kernel
     if world == 1 and not args.no_extras and not args.no_ic_extra and args.variant == "wc":
         # steady-state CG iteration cost on the ill-conditioned variant (23 iterations per subproblem): outside the timed region
         # (the first handle stays allocated: freeing 2 GiB here makes the driver scrub it in the background, which took

@@ -87,6 +87,7 @@ struct Ctx {
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
+    int64_t opt_ev_stride = 8;       // BH_FLAG_PROFILE: hipEvents around every opt_ev_stride-th H*p launch of a handle
     int64_t opt_pingpong = 0;        // alternate the sweep direction of J between consecutive H*p products (A/B: +1 % without nt loads, -0.2 % with)
     // RCCL
     void* rccl_lib = nullptr;
@@ -260,7 +261,6 @@ int grid_for(int cfg, int64_t nrows) {
 }
 
 constexpr int kEvCap = 512;
-constexpr int kEvStride = 8;
 
 }  // namespace
 
@@ -483,12 +483,12 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
     RowStreamArgs a = rs_args(H, nrows, state);
     a.v = v_pad; a.partials = H->partials; a.reverse = reverse;
     a.negate = negate ? 1 : 0; a.negmask = negmask;
-    // BH_FLAG_PROFILE: hipEvents around every kEvStride-th H*p launch of this handle, counted ACROSS calls (an event pair
-    // costs ~10 us of stream time; timing every launch would slow the loop it measures by 3 %).
+    // BH_FLAG_PROFILE: hipEvents around every opt_ev_stride-th (default 8th) H*p launch of this handle, counted ACROSS calls
+    // (an event pair costs ~10 us of stream time; timing every launch would slow the loop it measures by 3 %).
     bool timed = false;
     int slot = -1;
     if ((g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0) {
-        if ((H->hmul_seq++ % kEvStride) == 0 && (int)H->ev_pending.size() < kEvCap) {
+        if ((H->hmul_seq++ % (uint64_t)g_ctx.opt_ev_stride) == 0 && (int)H->ev_pending.size() < kEvCap) {
             if (H->ev.empty()) {
                 H->ev.resize(2 * kEvCap, nullptr);
                 for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
@@ -945,6 +945,11 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "profile_stride")) {
+        if (value < 1) return fail(BH_ERR_INVALID_ARG, "profile_stride must be >= 1");
+        g_ctx.opt_ev_stride = value;
+        return BH_OK;
+    }
     if (!strcmp(key, "comm_path")) {
         if (value == 1 && !g_ctx.peer.active) return fail(BH_ERR_PRECONDITION, "comm_path = 1 needs the peer-buffer communicator (BH_COMM=ipc or both)");
         if (value == 0 && comm_active() && g_ctx.comm == nullptr) return fail(BH_ERR_PRECONDITION, "comm_path = 0 needs an RCCL communicator (BH_COMM=rccl or both)");

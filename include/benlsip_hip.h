@@ -251,7 +251,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "blocks_per_cu" accepts 0..8 (the partial-slab buffers hold 8 workgroups per CU); anything else is BH_ERR_INVALID_ARG
  *   "comm_path"      [0 with BH_COMM=rccl|both, 1 with BH_COMM=ipc] which communicator carries the all-reduces: 0 = RCCL,
  *                        1 = the one-shot peer-buffer exchange fused into the slab reduction (needs BH_COMM=ipc or both)
- *   "profile"        [flags of bh_init] 1 = hipEvents around every 8th H*p launch (bh_stats: hmul_ms / hmul_timed) */
+ *   "profile"        [flags of bh_init] 1 = hipEvents around every profile_stride-th H*p launch (bh_stats: hmul_ms / hmul_timed)
+ *   "profile_stride" [8] >= 1; an event pair costs ~10 us of stream time, so 1 is for short runs only (at most 512 samples per call) */
 int32_t bh_set_option(const char* key, int64_t value);
 /* Time `reps` back-to-back launches of one kernel class with hipEvents on the launch stream.
  * kind: 0 = fused J'(Jp), 1 = J·v, 2 = J'·u; 3..6 = read-only stream probe over the same image (nothing but 16-byte

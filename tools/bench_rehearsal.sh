@@ -1,13 +1,16 @@
 #!/bin/bash
-# GPU box (one GPU): rehearse bench.py's N = 2 flow — two ranks on device 0, gloo for torch, host-staged all-reduce.
+# GPU box (one GPU): rehearse bench.py's N > 1 flow — all ranks on device 0, gloo for torch, the library's all-reduce over its
+# peer-buffer transport (hipIpc between processes on one device).  Exercises the script's multi-rank flow; not a measurement.
 R=$GRAFT_REPO_ROOT
 cd $R
-g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/multirank/staged_rccl.cpp \
-    -o tests/multirank/libstaged_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
-export BH_BENCH_REHEARSAL=1 BH_RCCL_LIB=$R/tests/multirank/libstaged_rccl.so BH_STAGED_RCCL_SHM=/bh_rehearsal_$$
-timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-    bench.py --gpus 2 --steps 20 --warmup 2 > gpurun_out/bench_rehearsal.log 2>&1
-rc=$?
-rm -f /dev/shm$BH_STAGED_RCCL_SHM
-tail -3 gpurun_out/bench_rehearsal.log | cut -c1-1500
+mkdir -p gpurun_out
+export BH_BENCH_REHEARSAL=1 BH_COMM=ipc
+rc=0
+for cfg in "2 weak" "3 strong"; do
+    set -- $cfg
+    timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port 2953$1 \
+        bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2.log 2>&1 || rc=$?
+    tail -1 gpurun_out/bench_rehearsal_$1_$2.log | cut -c1-1800
+    [ $rc -eq 0 ] || { tail -30 gpurun_out/bench_rehearsal_$1_$2.log; exit $rc; }
+done
 exit $rc
