@@ -1005,8 +1005,8 @@ def test_full_solve_medium_nls_through_c_abi(bh, capsys):
               "per operator %s; closest CG branch margin of the solve %.2e (%s)"
               % (sh.minor, len(sh.events), {k: float("%.1e" % v) for k, v in sh.worst.items()}, sh.min_margin[0],
                  None if sh.min_margin[1] is None else "minor iterate %d, test %s" % (sh.min_margin[1]["minor"], bh.operators.TIE_KINDS.get(sh.min_margin[1]["min_margin_kind"]))))
-        for e in sh.events[:5]:
-            print("        ", e)
+        for e in sorted(sh.events, key=lambda e: -e["rel"])[:3]:
+            print("        largest:", {k: v for k, v in e.items() if k != "operands"})
     check_shadow_events(sh)
 
 
