@@ -19,7 +19,7 @@ BH_UNIQUE_ID_BYTES = 128
 EXPORTS = [
     "bh_init", "bh_shutdown", "bh_set_stream", "bh_synchronize", "bh_strerror", "bh_last_error_detail", "bh_device_info",
     "bh_comm_unique_id", "bh_comm_init", "bh_comm_destroy", "bh_comm_info",
-    "bh_hess_create", "bh_hess_create_dev", "bh_hess_create_synthetic", "bh_hess_set_mu", "bh_hess_destroy", "bh_hess_shape",
+    "bh_hess_create", "bh_hess_create_async", "bh_hess_wait", "bh_hess_create_dev", "bh_hess_create_synthetic", "bh_hess_set_mu", "bh_hess_destroy", "bh_hess_shape",
     "bh_hmul", "bh_vthv", "bh_jv", "bh_jtv", "bh_hmul_dev", "bh_jv_dev", "bh_jtv_dev",
     "bh_proj_create", "bh_proj_set_active", "bh_proj_destroy", "bh_proj_shape", "bh_project", "bh_project_dev",
     "bh_left_mul", "bh_left_mul_tr",
@@ -58,6 +58,8 @@ _PROTOS = {
     "bh_comm_destroy": ([], _i32),
     "bh_comm_info": ([C.POINTER(_i32), C.POINTER(_i32)], _i32),
     "bh_hess_create": ([C.POINTER(_vp), _vp, _i64, _i64, _i64, _vp, _i64, _i64, _f64], _i32),
+    "bh_hess_create_async": ([C.POINTER(_vp), _vp, _i64, _i64, _i64, _vp, _i64, _i64, _f64], _i32),
+    "bh_hess_wait": ([_vp], _i32),
     "bh_hess_create_dev": ([C.POINTER(_vp), _vp, _i64, _i64, _i64, _vp, _i64, _i64, _f64], _i32),
     "bh_hess_create_synthetic": ([C.POINTER(_vp), _i64, _i64, _i64, _i64, C.c_uint64, _vp, _f64], _i32),
     "bh_hess_set_mu": ([_vp, _f64], _i32),

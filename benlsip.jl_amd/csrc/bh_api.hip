@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace bh;
@@ -87,6 +88,7 @@ struct Ctx {
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
+    int64_t opt_upload_chunk_mb = 64; // bh_hess_create_async: MiB of J per pipelined column chunk
     int64_t opt_ev_stride = 8;       // BH_FLAG_PROFILE: hipEvents around every opt_ev_stride-th H*p launch of a handle
     int64_t opt_pingpong = 0;        // alternate the sweep direction of J between consecutive H*p products (A/B: +1 % without nt loads, -0.2 % with)
     // RCCL
@@ -267,8 +269,21 @@ constexpr int kEvCap = 512;
 // ------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------
+// An upload in flight (bh_hess_create_async): a worker thread feeds column chunks of the caller's J through two device
+// staging buffers — copy of chunk k+1 on one stream while chunk k is transposed into the row-major image on another.
+struct AsyncUpload {
+    std::thread worker;
+    int32_t rc = BH_OK;              // written by the worker, read after join
+    std::string detail;
+    hipStream_t s_copy = nullptr, s_xpose = nullptr;
+    double* staging[2] = {nullptr, nullptr};
+    hipEvent_t copied[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
+    int64_t chunk_cols = 0;
+};
+
 struct bh_hess {
     int64_t d = 0, n = 0, q = 0, q_eff = 0, ld = 0;
+    AsyncUpload* up = nullptr;     // non-NULL while bh_hess_create_async's upload may still be running (hess_ready joins it)
     int64_t d_total = 0;           // rows of J over all ranks (= d on one rank): sizes the launch-ahead batch identically everywhere
     int nchunks = 0;
     double mu = 0.0;
@@ -347,6 +362,7 @@ int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
 
 struct MirrorWord { int done, status, iter, n_hmul; };
 int32_t check_peer_error();
+int32_t hess_ready(bh_hess* H);
 
 // Spin on the host-mapped progress word until this call's tag shows `done` or at least `target` H*p products.
 int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
@@ -472,6 +488,7 @@ int32_t launch_jtv_panels(bh_hess* H, const double* u, double* z_out, int64_t nr
 // z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
 int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0,
                     bool negate = false, const int* negmask = nullptr) {
+    BH_TRY(hess_ready(H));
     const int64_t nrows = H->d + H->q_eff;
     if (multi_panel(H)) {
         BH_TRY(launch_jv_panels(H, v_pad, H->tbuf, nrows, state));
@@ -505,6 +522,7 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
 }
 
 int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_rows, double* sq_out_scalar) {
+    BH_TRY(hess_ready(H));
     const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
     if (multi_panel(H)) {
         double* t = t_out ? t_out : H->tbuf;
@@ -528,6 +546,7 @@ int32_t launch_jv(bh_hess* H, const double* v_pad, double* t_out, bool with_c_ro
 }
 
 int32_t launch_jtv(bh_hess* H, const double* u_dev, double* z_out, bool with_c_rows = false) {
+    BH_TRY(hess_ready(H));
     const int64_t nrows = H->d + (with_c_rows ? H->q_eff : 0);
     if (multi_panel(H)) {
         BH_TRY(launch_jtv_panels(H, u_dev, z_out, nrows, false, nullptr));
@@ -563,6 +582,62 @@ int32_t alloc_hess_common(bh_hess* H) {
     return BH_OK;
 }
 
+int32_t finish_hess_create(bh_hess* H);
+
+static void async_upload_cleanup(AsyncUpload* u) {
+    for (int i = 0; i < 2; ++i) {
+        if (u->copied[i]) (void)hipEventDestroy(u->copied[i]);
+        if (u->freed[i]) (void)hipEventDestroy(u->freed[i]);
+        dev_free(u->staging[i]);
+    }
+    if (u->s_copy) (void)hipStreamDestroy(u->s_copy);
+    if (u->s_xpose) (void)hipStreamDestroy(u->s_xpose);
+}
+
+// Worker of bh_hess_create_async.  Never touches g_ctx.detail (the caller's thread owns it): errors travel in u.rc / u.detail.
+static void async_upload_worker(bh_hess* H, const double* J, int64_t d, int64_t n, int64_t ldJ, int device) {
+    AsyncUpload& u = *H->up;
+    auto bad = [&](const char* what, hipError_t e) { u.rc = BH_ERR_HIP; u.detail = std::string(what) + ": " + hipGetErrorString(e); };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { bad("hipSetDevice (upload thread)", e); return; }
+    const int64_t cc = u.chunk_cols;
+    int k = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += cc, ++k) {
+        const int slot = k & 1;
+        const int64_t cols = std::min(cc, n - c0);
+        const bool last = c0 + cols >= n;
+        // the staging slot is free once the transpose that read it (two chunks ago) has finished
+        if (k >= 2 && (e = hipEventSynchronize(u.freed[slot])) != hipSuccess) { bad("hipEventSynchronize", e); return; }
+        if (ldJ == d) e = hipMemcpyAsync(u.staging[slot], J + c0 * ldJ, (size_t)d * cols * sizeof(double), hipMemcpyHostToDevice, u.s_copy);
+        else e = hipMemcpy2DAsync(u.staging[slot], (size_t)d * sizeof(double), J + c0 * ldJ, (size_t)ldJ * sizeof(double),
+                                  (size_t)d * sizeof(double), (size_t)cols, hipMemcpyHostToDevice, u.s_copy);
+        if (e != hipSuccess) { bad("hipMemcpyAsync (J chunk)", e); return; }
+        if ((e = hipEventRecord(u.copied[slot], u.s_copy)) != hipSuccess) { bad("hipEventRecord", e); return; }
+        if ((e = hipStreamWaitEvent(u.s_xpose, u.copied[slot], 0)) != hipSuccess) { bad("hipStreamWaitEvent", e); return; }
+        const int64_t wcols = last ? H->ld - c0 : cols;          // the last chunk also writes the zero padding of every row
+        dim3 grid((unsigned)((d + 31) / 32), (unsigned)((wcols + 31) / 32));
+        hipLaunchKernelGGL(transpose_cm_to_rm_kernel, grid, dim3(256), 0, u.s_xpose, (const double*)u.staging[slot], d, d, cols,
+                           H->Jd + c0, H->ld, wcols);
+        if ((e = hipGetLastError()) != hipSuccess) { bad("transpose launch", e); return; }
+        if ((e = hipEventRecord(u.freed[slot], u.s_xpose)) != hipSuccess) { bad("hipEventRecord", e); return; }
+    }
+    if ((e = hipStreamSynchronize(u.s_xpose)) != hipSuccess) bad("hipStreamSynchronize (upload)", e);
+}
+
+// Every entry point that reads the image calls this first: joins a pending asynchronous upload (bh_hess_wait does the same).
+int32_t hess_ready(bh_hess* H) {
+    if (!H || !H->up) return BH_OK;
+    AsyncUpload* u = H->up;
+    if (u->worker.joinable()) u->worker.join();
+    const int32_t rc = u->rc;
+    const std::string detail = u->detail;
+    async_upload_cleanup(u);
+    delete u;
+    H->up = nullptr;
+    if (rc != BH_OK) return fail(rc, "asynchronous J upload: " + detail);
+    return finish_hess_create(H);
+}
+
 // Last step of every bh_hess constructor.  With a communicator the ranks' row counts are summed once: everything that
 // shapes the launch schedule (launch_batch_size) must be computed from data that is identical on all ranks, or ranks would
 // enqueue different numbers of iterations — and of collectives (q_eff and the +-1 row of row_shard differ between ranks).
@@ -586,7 +661,7 @@ int32_t finish_hess_create(bh_hess* H) {
 int32_t transpose_from_device(const double* src_dev, int64_t rows, int64_t cols, int64_t lds, double* dst_image, int64_t row0, int64_t ldd) {
     if (rows == 0) return BH_OK;
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((ldd + 31) / 32));
-    hipLaunchKernelGGL(transpose_cm_to_rm_kernel, grid, dim3(256), 0, g_ctx.stream, src_dev, lds, rows, cols, dst_image + row0 * ldd, ldd);
+    hipLaunchKernelGGL(transpose_cm_to_rm_kernel, grid, dim3(256), 0, g_ctx.stream, src_dev, lds, rows, cols, dst_image + row0 * ldd, ldd, ldd);
     BH_HIP(hipGetLastError());
     return BH_OK;
 }
@@ -603,7 +678,7 @@ int32_t upload_transposed(const double* host, int64_t rows, int64_t cols, int64_
     }
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((ldd + 31) / 32));
     hipLaunchKernelGGL(transpose_cm_to_rm_kernel, grid, dim3(256), 0, g_ctx.stream, staging, rows, rows, cols,
-                       dst_image + row0 * ldd, ldd);
+                       dst_image + row0 * ldd, ldd, ldd);
     hipError_t e = hipStreamSynchronize(g_ctx.stream);
     dev_free(staging);
     if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("transpose: ") + hipGetErrorString(e));
@@ -945,6 +1020,11 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "upload_chunk_mb")) {
+        if (value < 1 || value > 4096) return fail(BH_ERR_INVALID_ARG, "upload_chunk_mb must be 1..4096");
+        g_ctx.opt_upload_chunk_mb = value;
+        return BH_OK;
+    }
     if (!strcmp(key, "profile_stride")) {
         if (value < 1) return fail(BH_ERR_INVALID_ARG, "profile_stride must be >= 1");
         g_ctx.opt_ev_stride = value;
@@ -1213,6 +1293,59 @@ int32_t bh_hess_create_dev(bh_hess** out, const double* J_dev, int64_t d, int64_
     return BH_OK;
 }
 
+// f-4: the same upload without blocking the caller.  J must stay valid and unchanged until bh_hess_wait (or the first use
+// of the handle, which waits implicitly) returns.
+int32_t bh_hess_create_async(bh_hess** out, const double* J, int64_t d, int64_t n, int64_t ldJ, const double* C, int64_t q,
+                             int64_t ldC, double mu) {
+    BH_REQUIRE_INIT();
+    if (!out) return fail(BH_ERR_INVALID_ARG, "NULL out");
+    *out = nullptr;
+    if (d < 0 || n < 1 || q < 0) return fail(BH_ERR_INVALID_ARG, "negative dimension");
+    if (d > 0 && (!J || ldJ < d)) return fail(BH_ERR_INVALID_ARG, "J NULL or ldJ < d");
+    if (q > 0 && (!C || ldC < q)) return fail(BH_ERR_INVALID_ARG, "C NULL or ldC < q");
+    bh_hess* H = new bh_hess();
+    H->d = d; H->n = n; H->q = q; H->mu = mu;
+    int32_t rc = alloc_hess_common(H);
+    if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);      // the C block is small: synchronous
+    if (rc == BH_OK && hipStreamSynchronize(g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "bh_hess_create_async: synchronize");
+    if (rc == BH_OK && d > 0) {
+        AsyncUpload* u = new AsyncUpload();
+        H->up = u;
+        // column chunks of ~upload_chunk_mb MiB, a multiple of 32 columns (the transpose's tile width)
+        int64_t cc = (g_ctx.opt_upload_chunk_mb << 20) / (8 * std::max<int64_t>(d, 1));
+        cc = std::max<int64_t>(32, cc / 32 * 32);
+        u->chunk_cols = std::min<int64_t>(cc, round_up(n, 32));
+        bool ok = hipStreamCreateWithFlags(&u->s_copy, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&u->s_xpose, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) {
+            ok = hipEventCreateWithFlags(&u->copied[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&u->freed[i], hipEventDisableTiming) == hipSuccess &&
+                 hipMalloc(reinterpret_cast<void**>(&u->staging[i]), (size_t)d * u->chunk_cols * sizeof(double)) == hipSuccess;
+        }
+        if (!ok) {
+            async_upload_cleanup(u);
+            delete u;
+            H->up = nullptr;
+            rc = fail(BH_ERR_HIP, "bh_hess_create_async: streams / events / staging buffers");
+        } else {
+            u->worker = std::thread(async_upload_worker, H, J, d, n, ldJ, g_ctx.device);
+        }
+    } else if (rc == BH_OK) {
+        rc = finish_hess_create(H);
+    }
+    if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
+    *out = H;
+    H->counted = true;
+    g_ctx.live_hess += 1;
+    return BH_OK;
+}
+
+int32_t bh_hess_wait(bh_hess* H) {
+    BH_REQUIRE_INIT();
+    if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    return hess_ready(H);
+}
+
 int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t row0, int64_t d_total, uint64_t seed,
                                  const double* colscale, double mu) {
     BH_REQUIRE_INIT();
@@ -1251,6 +1384,13 @@ int32_t bh_hess_set_mu(bh_hess* H, double mu) {
 
 int32_t bh_hess_destroy(bh_hess* H) {
     if (!H) return BH_OK;
+    if (H->up) {                              // an upload still in flight: let it finish before its buffers go
+        AsyncUpload* u = H->up;
+        if (u->worker.joinable()) u->worker.join();
+        async_upload_cleanup(u);
+        delete u;
+        H->up = nullptr;
+    }
     if (H->counted) g_ctx.live_hess -= 1;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(H->Jd); dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf);
@@ -2001,6 +2141,7 @@ int32_t bh_stats_reset(bh_hess* H) {
 int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
     BH_REQUIRE_INIT();
     if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 8) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    BH_TRY(hess_ready(H));
     if (kind == 7 && !comm_active()) return fail(BH_ERR_PRECONDITION, "bh_time_kernel(7): no communicator (bh_comm_init; BH_FORCE_COMM=1 for one rank)");
     hipEvent_t e0, e1;
     BH_HIP(hipEventCreate(&e0));

@@ -258,8 +258,10 @@ __global__ __launch_bounds__(1024) void weighted_sqsum_kernel(const double* __re
 }
 
 // Column-major (host layout, leading dimension lds) -> row-major padded image.  32x32 tiles via LDS.
+// wcols: destination columns written per row, counted from dst (>= cols; columns [cols, wcols) are zero padding) — a
+// column chunk of a larger image writes only its own columns (bh_hess_create_async), a whole image passes wcols = ldd.
 __global__ __launch_bounds__(256) void transpose_cm_to_rm_kernel(const double* __restrict__ src, int64_t lds_, int64_t rows,
-                                                                 int64_t cols, double* __restrict__ dst, int64_t ldd) {
+                                                                 int64_t cols, double* __restrict__ dst, int64_t ldd, int64_t wcols) {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void transpose_cm_to_rm_kernel(const double* _
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t r = r0 + ty + 8 * k, c = c0 + tx;
-        if (r < rows && c < ldd) dst[r * ldd + c] = (c < cols) ? tile[tx][ty + 8 * k] : 0.0;
+        if (r < rows && c < wcols) dst[r * ldd + c] = (c < cols) ? tile[tx][ty + 8 * k] : 0.0;
     }
 }
 

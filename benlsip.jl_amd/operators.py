@@ -68,6 +68,29 @@ class AlHessian:
         self._mu = float(mu)
 
     @classmethod
+    def create_async(cls, J, C=None, mu=0.0):
+        """``bh_hess_create_async``: returns while J is still on its way to HBM (chunked copy overlapped with the device
+        transpose); ``wait()`` — or the first product — joins the upload.  The object keeps ``J`` alive until then."""
+        lib = _lib.lib()
+        self = cls.__new__(cls)
+        Jf = np.asfortranarray(np.asarray(J, dtype=np.float64))
+        d, n = Jf.shape
+        Cm = np.zeros((0, n)) if C is None else np.asarray(C, dtype=np.float64)
+        q = Cm.shape[0]
+        Cf = np.asfortranarray(Cm)
+        self._h = _null_handle()
+        self._pending_J = Jf
+        check(lib.bh_hess_create_async(_byref(self._h), ptr(Jf) if d > 0 else None, d, n, max(d, 1), ptr(Cf) if q > 0 else None, q,
+                                       max(q, 1), float(mu)), "bh_hess_create_async")
+        self.d, self.n, self.q = d, n, q
+        self._mu = float(mu)
+        return self
+
+    def wait(self):
+        check(_lib.lib().bh_hess_wait(self._h), "bh_hess_wait")
+        self._pending_J = None
+
+    @classmethod
     def from_device(cls, J_dev_ptr, d, n, ldJ=None, C=None, mu=0.0):
         """J already in HBM (column-major d x n at device address ``J_dev_ptr``, e.g. ``tensor.data_ptr()`` or a
         ``DeviceVector.ptr``): only the device transpose runs (``bh_hess_create_dev``)."""

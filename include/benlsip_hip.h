@@ -118,6 +118,16 @@ int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int
  * C (q x n) stays a host pointer. */
 int32_t bh_hess_create_dev(bh_hess** out, const double* J_dev, int64_t d, int64_t n, int64_t ldJ,
                            const double* C, int64_t q, int64_t ldC, double mu);
+/* Asynchronous ingest: like bh_hess_create, but returns as soon as the upload has been started.  A worker
+ * thread streams J in column chunks (option "upload_chunk_mb", default 64 MiB) through two device staging buffers: the PCIe
+ * copy of chunk k+1 overlaps the device transpose of chunk k, and both overlap whatever the caller does next on the host
+ * (the reference evaluates the residuals and the constraints of the next point there, src/basic_tralcnlss.jl:352).
+ * J must stay valid and unchanged until bh_hess_wait — or the first use of the handle, which waits implicitly — returns;
+ * C is small and is copied before the call returns.  With a communicator every rank must call bh_hess_wait (or make its
+ * first use of the handle) at the same point of its call sequence. */
+int32_t bh_hess_create_async(bh_hess** out, const double* J, int64_t d, int64_t n, int64_t ldJ,
+                             const double* C, int64_t q, int64_t ldC, double mu);
+int32_t bh_hess_wait(bh_hess* H);
 /* Benchmark constructor: rows [row0, row0+d) of the d_total x n synthetic Jacobian of SURVEY.md §8(d),
  * element (i,j) = u(seed, i + j*d_total)/sqrt(d_total) * (colscale ? colscale[j] : 1), generated in HBM. */
 int32_t bh_hess_create_synthetic(bh_hess** out, int64_t d, int64_t n, int64_t row0, int64_t d_total,
@@ -252,6 +262,7 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "comm_path"      [0 with BH_COMM=rccl|both, 1 with BH_COMM=ipc] which communicator carries the all-reduces: 0 = RCCL,
  *                        1 = the one-shot peer-buffer exchange fused into the slab reduction (needs BH_COMM=ipc or both)
  *   "profile"        [flags of bh_init] 1 = hipEvents around every profile_stride-th H*p launch (bh_stats: hmul_ms / hmul_timed)
+ *   "upload_chunk_mb" [64] bh_hess_create_async: MiB of J per pipelined column chunk (1..4096)
  *   "profile_stride" [8] >= 1; an event pair costs ~10 us of stream time, so 1 is for short runs only (at most 512 samples per call) */
 int32_t bh_set_option(const char* key, int64_t value);
 /* Time `reps` back-to-back launches of one kernel class with hipEvents on the launch stream.

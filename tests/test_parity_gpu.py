@@ -830,18 +830,65 @@ def test_pcg_config3_full_size_against_oracle(bh):
 
 
 def test_hessian_from_device_resident_jacobian(bh):
-    """bh_hess_create_dev (f-4: a device-side jac_res hands over J in HBM): same image as the host upload."""
+    """bh_hess_create_dev (f-4: a device-side jac_res hands over J in HBM; only the transpose runs): the products of the
+    resulting image against the ORACLE's on the same J, C — and, as a layout check, bit-equal to the host-upload handle's."""
     rng = np.random.default_rng(9)
-    d, n, q = 300, 130, 2
-    J, C = rng.standard_normal((d, n)), rng.standard_normal((q, n))
-    Jf = np.asfortranarray(J)
-    buf = bh.DeviceVector(d * n, Jf.ravel(order="F"))
-    H_dev = bh.AlHessian.from_device(buf.ptr, d, n, C=C, mu=3.0)
-    H_host = bh.AlHessian(J, C, 3.0)
-    v = rng.standard_normal(n)
-    assert np.array_equal(H_dev * v, H_host * v)
-    assert np.array_equal(H_dev.jv(v), H_host.jv(v))
-    assert bh.vthv(H_dev, v) == bh.vthv(H_host, v)
+    for d, n, q, ld_extra in ((300, 130, 2, 0), (257, 65, 0, 7), (1, 40, 1, 0)):
+        J, C = rng.standard_normal((d, n)), rng.standard_normal((q, n))
+        ldJ = d + ld_extra                                         # a Jacobian that is a view into a taller device buffer
+        Jbuf = np.full((ldJ, n), np.nan, order="F")
+        Jbuf[:d] = J
+        buf = bh.DeviceVector(ldJ * n, Jbuf.ravel(order="F"))
+        H_dev = bh.AlHessian.from_device(buf.ptr, d, n, ldJ=ldJ, C=C, mu=3.0)
+        Ho = R.AlHessian(J, C, 3.0)
+        v, u = rng.standard_normal(n), rng.standard_normal(d)
+        scale = np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(v)) + 3.0 * np.abs(C).T @ (np.abs(C) @ np.abs(v)))
+        assert np.linalg.norm(H_dev * v - R.hmul(Ho, v)) <= TOL1 * scale
+        assert np.linalg.norm(H_dev.jv(v) - J @ v) <= TOL1 * matvec_scale(J, v)
+        assert np.linalg.norm(H_dev.jtv(u) - J.T @ u) <= TOL1 * matvec_scale(J.T, u)
+        assert bh.vthv(H_dev, v) == pytest.approx(R.vthv(Ho, v), rel=1e-12)
+        H_host = bh.AlHessian(J, C, 3.0)
+        assert np.array_equal(H_dev * v, H_host * v) and np.array_equal(H_dev.jtv(u), H_host.jtv(u))
+        H_dev.close(); H_host.close(); buf.close()
+
+
+@pytest.mark.parametrize("d,n,q,chunk_mb", [(3000, 700, 2, 1), (513, 4100, 0, 1), (40, 33, 1, 64), (70000, 96, 0, 8)])
+def test_asynchronous_jacobian_ingest(bh, d, n, q, chunk_mb):
+    """bh_hess_create_async / bh_hess_wait (f-4): J travels in pipelined column chunks (copy of chunk k+1 over the transpose
+    of chunk k) while the caller keeps working; the image must give the ORACLE's products, also when the first use of the
+    handle is what joins the upload, and a projected_cg on it must match the oracle's."""
+    rng = np.random.default_rng(d + n)
+    J, C = rng.standard_normal((d, n)) / np.sqrt(d), rng.standard_normal((q, n))
+    bh.set_option("upload_chunk_mb", chunk_mb)
+    try:
+        H = bh.AlHessian.create_async(J, C, 2.0)
+        Ho = R.AlHessian(J, C, 2.0)                               # host work while the upload runs
+        v, u = rng.standard_normal(n), rng.standard_normal(d)
+        ref_hv, ref_jv, ref_jtu = R.hmul(Ho, v), J @ v, J.T @ u
+        H.wait()
+        scale = np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(v)) + 2.0 * np.abs(C).T @ (np.abs(C) @ np.abs(v)))
+        assert np.linalg.norm(H * v - ref_hv) <= TOL1 * scale
+        assert np.linalg.norm(H.jv(v) - ref_jv) <= TOL1 * matvec_scale(J, v)
+        assert np.linalg.norm(H.jtv(u) - ref_jtu) <= TOL1 * matvec_scale(J.T, u)
+        H2 = bh.AlHessian.create_async(J, C, 2.0)                 # no explicit wait: the first product joins the upload
+        assert np.array_equal(H2 * v, H * v)
+        H_sync = bh.AlHessian(J, C, 2.0)
+        assert np.array_equal(H_sync * v, H * v) and np.array_equal(H_sync.jtv(u), H.jtv(u))
+        H3 = bh.AlHessian.create_async(J, C, 2.0)                 # destroyed while the upload may still be in flight
+        H3.close()
+        if n <= 1024:
+            A = np.zeros((0, n))
+            fix = np.zeros(n, dtype=bool)
+            fix[::7] = True
+            cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix, l=-np.ones(n), u=np.ones(n))
+            g = J.T @ rng.standard_normal(d)
+            w_l, w_u = R.build_step_bounds(np.where(fix, 1.0, 0.0), cons_o, 0.5)
+            w_ref, st_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
+            w, st, info = bh.projected_cg(g, H, w_l, w_u, bh.MixedConstraints(A, None, fix), 0.1, full_output=True)
+            assert int(st) == int(st_ref) and info["iters"] == it_ref
+            assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+    finally:
+        bh.set_option("upload_chunk_mb", 64)
 
 
 def test_inner_step_device_chain_against_oracle(bh, capsys):
