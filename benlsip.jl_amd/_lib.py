@@ -24,6 +24,8 @@ EXPORTS = [
     "bh_proj_create", "bh_proj_set_active", "bh_proj_destroy", "bh_proj_shape", "bh_project", "bh_project_dev",
     "bh_left_mul", "bh_left_mul_tr",
     "bh_pcg", "bh_pcg_dev", "bh_pcg_tie_info", "bh_resid_sqnorm", "bh_factor_to_boundary", "bh_minor_iterate", "bh_linesearch", "bh_grad", "bh_hmul_add", "bh_cauchy_step",
+    "bh_cauchy_step_dev", "bh_minor_iterate_dev", "bh_linesearch_dev", "bh_grad_dev", "bh_hmul_add_dev", "bh_step_accumulate_dev",
+    "bh_proj_update_active_dev", "bh_reduced_gradient_norm_dev", "bh_model_reduction_dev",
     "bh_dev_alloc", "bh_dev_free", "bh_dev_upload", "bh_dev_download", "bh_stats", "bh_stats_reset",
     "bh_set_option", "bh_time_kernel", "bh_selftest",
 ]
@@ -38,7 +40,8 @@ class BenlsipHipError(RuntimeError):
 class bh_stats_t(C.Structure):
     _fields_ = [("n_hmul", C.c_int64), ("n_jv", C.c_int64), ("n_jtv", C.c_int64), ("n_proj", C.c_int64),
                 ("n_pcg", C.c_int64), ("n_cg_iter", C.c_int64), ("n_allreduce", C.c_int64), ("hmul_ms", C.c_double),
-                ("hmul_timed", C.c_int64), ("bytes_per_hmul", C.c_double)]
+                ("hmul_timed", C.c_int64), ("bytes_per_hmul", C.c_double),
+                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("h2d_calls", C.c_int64), ("d2h_calls", C.c_int64)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -92,6 +95,16 @@ _PROTOS = {
     "bh_linesearch": ([_vp, _vp, _vp, _vp, _vp, _vp, _dp], _i32),
     "bh_cauchy_step": ([_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, C.POINTER(_i32), C.POINTER(_i32)], _i32),
     "bh_grad": ([_vp, _vp, _vp, _vp], _i32),
+    "bh_cauchy_step_dev": ([_vp, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, C.POINTER(_i32), C.POINTER(_i32)], _i32),
+    "bh_minor_iterate_dev": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _f64, _f64, _vp, C.POINTER(_i32), C.POINTER(_i32),
+                             C.POINTER(_i32), _dp], _i32),
+    "bh_linesearch_dev": ([_vp, _vp, _vp, _vp, _vp, _vp, _dp], _i32),
+    "bh_grad_dev": ([_vp, _vp, _vp, _vp], _i32),
+    "bh_hmul_add_dev": ([_vp, _vp, _vp, _vp], _i32),
+    "bh_step_accumulate_dev": ([_vp, _vp, _vp, _vp, _vp], _i32),
+    "bh_proj_update_active_dev": ([_vp, _vp, _vp, _vp, _vp, _f64, _f64, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp], _i32),
+    "bh_reduced_gradient_norm_dev": ([_vp, _vp, _dp], _i32),
+    "bh_model_reduction_dev": ([_vp, _vp, _vp, _dp], _i32),
     "bh_hmul_add": ([_vp, _vp, _vp, _vp], _i32),
     "bh_dev_alloc": ([C.POINTER(_vp), _i64], _i32),
     "bh_dev_free": ([_vp], _i32),

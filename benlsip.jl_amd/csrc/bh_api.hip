@@ -65,6 +65,20 @@ constexpr int kPeerBlkCap = (int)(kPeerCap / (2 * kPeerBlockChunks));   // 2048 
 constexpr size_t kPeerSlotBytes = (size_t)2 * kMaxPeers * kPeerCap * sizeof(double);
 constexpr size_t kPeerFlagBytes = (size_t)2 * kMaxPeers * kPeerBlkCap * sizeof(unsigned long long);
 
+// An upload in flight (bh_hess_create_async): a worker thread feeds column chunks of the caller's J through two device
+// staging buffers — copy of chunk k+1 on one stream while chunk k is transposed into the row-major image on another.
+struct AsyncUpload {
+    std::thread worker;
+    int32_t rc = BH_OK;              // written by the worker, read after join
+    std::string detail;
+    hipStream_t s_copy = nullptr, s_xpose = nullptr;
+    double* staging[2] = {nullptr, nullptr};
+    hipEvent_t copied[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
+    size_t staging_bytes = 0;        // capacity of each staging buffer
+    int64_t chunk_cols = 0;
+    bool resources() const { return s_copy != nullptr; }
+};
+
 struct Ctx {
     bool init = false;
     int device = -1;
@@ -105,6 +119,9 @@ struct Ctx {
     int comm_path = 0;
     CgWorkspace cg;
     double* scratch_dev = nullptr;   // small device scratch (selftest, f2b)
+    AsyncUpload* upload_cache = nullptr;   // streams, events and staging buffers of the last finished asynchronous upload, kept for the next
+    // host <-> device traffic issued by the library since bh_init (bh_stats: the device-resident entry points are checked against it)
+    int64_t h2d_bytes = 0, d2h_bytes = 0, h2d_calls = 0, d2h_calls = 0;
     double* rbuf = nullptr;          // residual staging of bh_resid_sqnorm (grown on demand)
     int64_t rbuf_cap = 0;
     int live_hess = 0;               // bh_hess handles alive (a handle bakes in this rank's share of C: see bh_comm_init)
@@ -151,6 +168,8 @@ int32_t fail(int32_t code, const std::string& what, bool drain = true) {
 #define BH_TRY(expr) do { int32_t rc__ = (expr); if (rc__ != BH_OK) return rc__; } while (0)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline void count_h2d(size_t bytes) { g_ctx.h2d_bytes += (int64_t)bytes; g_ctx.h2d_calls += 1; }
+inline void count_d2h(size_t bytes) { g_ctx.d2h_bytes += (int64_t)bytes; g_ctx.d2h_calls += 1; }
 
 template <class T>
 int32_t dev_alloc(T** out, int64_t count) {
@@ -269,18 +288,6 @@ constexpr int kEvCap = 512;
 // ------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------
-// An upload in flight (bh_hess_create_async): a worker thread feeds column chunks of the caller's J through two device
-// staging buffers — copy of chunk k+1 on one stream while chunk k is transposed into the row-major image on another.
-struct AsyncUpload {
-    std::thread worker;
-    int32_t rc = BH_OK;              // written by the worker, read after join
-    std::string detail;
-    hipStream_t s_copy = nullptr, s_xpose = nullptr;
-    double* staging[2] = {nullptr, nullptr};
-    hipEvent_t copied[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
-    int64_t chunk_cols = 0;
-};
-
 struct bh_hess {
     int64_t d = 0, n = 0, q = 0, q_eff = 0, ld = 0;
     AsyncUpload* up = nullptr;     // non-NULL while bh_hess_create_async's upload may still be running (hess_ready joins it)
@@ -321,7 +328,11 @@ struct bh_proj {
     double* Lr = nullptr;          // mA x mA + mA: chol(M) and its reciprocal diagonal (reduced form)
     int* info = nullptr;           // device flag of chol_lower_kernel
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
+    bool M_valid = false;          // M = A_free A_free' for the CURRENT active set (false after factor-only downdates)
     std::vector<uint64_t> last_chunks;   // fixvars of the last successful bh_proj_set_active (reduced form: skip identical pushes)
+    int* newidx = nullptr;         // n ints: variables fixed by the last bh_proj_update_active_dev, index order
+    int* counts = nullptr;         // 8 ints (AU_*)
+    unsigned long long* chunks_dev = nullptr;   // ceil(n/64) + 1 words: BitVector image of the device-side mask
     double* tw = nullptr;          // n + 16
     double* rpad = nullptr;        // ldA
     double* vtmp = nullptr;        // ldA
@@ -584,7 +595,8 @@ int32_t alloc_hess_common(bh_hess* H) {
 
 int32_t finish_hess_create(bh_hess* H);
 
-static void async_upload_cleanup(AsyncUpload* u) {
+static void async_upload_destroy(AsyncUpload* u) {
+    if (!u) return;
     for (int i = 0; i < 2; ++i) {
         if (u->copied[i]) (void)hipEventDestroy(u->copied[i]);
         if (u->freed[i]) (void)hipEventDestroy(u->freed[i]);
@@ -592,6 +604,17 @@ static void async_upload_cleanup(AsyncUpload* u) {
     }
     if (u->s_copy) (void)hipStreamDestroy(u->s_copy);
     if (u->s_xpose) (void)hipStreamDestroy(u->s_xpose);
+    delete u;
+}
+// A finished upload hands its streams / events / staging buffers to the next one (creating them costs ~3 ms, hipFree of the
+// staging buffers another ~3 ms: more than a 64 MiB upload itself).
+static void async_upload_cleanup(AsyncUpload* u) {
+    if (g_ctx.init && g_ctx.upload_cache == nullptr && u->resources() && u->rc == BH_OK) {
+        u->detail.clear();
+        g_ctx.upload_cache = u;
+        return;
+    }
+    async_upload_destroy(u);
 }
 
 // Worker of bh_hess_create_async.  Never touches g_ctx.detail (the caller's thread owns it): errors travel in u.rc / u.detail.
@@ -632,7 +655,6 @@ int32_t hess_ready(bh_hess* H) {
     const int32_t rc = u->rc;
     const std::string detail = u->detail;
     async_upload_cleanup(u);
-    delete u;
     H->up = nullptr;
     if (rc != BH_OK) return fail(rc, "asynchronous J upload: " + detail);
     return finish_hess_create(H);
@@ -672,6 +694,7 @@ int32_t upload_transposed(const double* host, int64_t rows, int64_t cols, int64_
     double* staging = nullptr;
     BH_TRY(dev_alloc(&staging, rows * std::max<int64_t>(cols, 1)));
     if (cols > 0) {
+        count_h2d((size_t)rows * cols * sizeof(double));
         hipError_t e = hipMemcpy2DAsync(staging, (size_t)rows * sizeof(double), host, (size_t)ldh * sizeof(double),
                                         (size_t)rows * sizeof(double), (size_t)cols, hipMemcpyHostToDevice, g_ctx.stream);
         if (e != hipSuccess) { dev_free(staging); return fail(BH_ERR_HIP, std::string("hipMemcpy2DAsync: ") + hipGetErrorString(e)); }
@@ -724,6 +747,7 @@ double* pin_alloc(int64_t n) {
 
 int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_device) {
     if (n == 0) return BH_OK;
+    if (!src_is_device) count_h2d((size_t)n * sizeof(double));
     if (!src_is_device) {
         if (double* pin = pin_alloc(n)) {
             memcpy(pin, src, (size_t)n * sizeof(double));
@@ -738,6 +762,7 @@ int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_dev
 
 int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_device) {
     if (n == 0) return BH_OK;
+    if (!dst_is_device) count_d2h((size_t)n * sizeof(double));
     if (!dst_is_device) {
         if (double* pin = pin_alloc(n)) {
             BH_HIP(hipMemcpyAsync(pin, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
@@ -827,6 +852,7 @@ int32_t launch_reduced_factor(bh_proj* P, bool use_mask, const CgState* gate) {
                            use_mask ? P->fixrank : (const int*)nullptr, P->M);
     }
     BH_TRY(launch_chol(P, gate));
+    P->M_valid = true;
     return BH_OK;
 }
 
@@ -973,6 +999,7 @@ int32_t bh_shutdown(void) {
     c = CgWorkspace();
     dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
     dev_free(g_ctx.rbuf); g_ctx.rbuf = nullptr; g_ctx.rbuf_cap = 0;
+    async_upload_destroy(g_ctx.upload_cache); g_ctx.upload_cache = nullptr;
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
     g_ctx.own_stream = nullptr; g_ctx.stream = nullptr;
     if (g_pin.base) { (void)hipHostFree(g_pin.base); g_pin = PinArena(); }
@@ -1309,25 +1336,33 @@ int32_t bh_hess_create_async(bh_hess** out, const double* J, int64_t d, int64_t 
     if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);      // the C block is small: synchronous
     if (rc == BH_OK && hipStreamSynchronize(g_ctx.stream) != hipSuccess) rc = fail(BH_ERR_HIP, "bh_hess_create_async: synchronize");
     if (rc == BH_OK && d > 0) {
-        AsyncUpload* u = new AsyncUpload();
-        H->up = u;
         // column chunks of ~upload_chunk_mb MiB, a multiple of 32 columns (the transpose's tile width)
         int64_t cc = (g_ctx.opt_upload_chunk_mb << 20) / (8 * std::max<int64_t>(d, 1));
         cc = std::max<int64_t>(32, cc / 32 * 32);
-        u->chunk_cols = std::min<int64_t>(cc, round_up(n, 32));
-        bool ok = hipStreamCreateWithFlags(&u->s_copy, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&u->s_xpose, hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < 2 && ok; ++i) {
-            ok = hipEventCreateWithFlags(&u->copied[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&u->freed[i], hipEventDisableTiming) == hipSuccess &&
-                 hipMalloc(reinterpret_cast<void**>(&u->staging[i]), (size_t)d * u->chunk_cols * sizeof(double)) == hipSuccess;
+        cc = std::min<int64_t>(cc, round_up(n, 32));
+        const size_t need = (size_t)d * cc * sizeof(double);
+        AsyncUpload* u = g_ctx.upload_cache;           // the previous upload's resources, if they are free and large enough
+        g_ctx.upload_cache = nullptr;
+        if (u && u->staging_bytes < need) { async_upload_destroy(u); u = nullptr; }
+        bool ok = true;
+        if (!u) {
+            u = new AsyncUpload();
+            ok = hipStreamCreateWithFlags(&u->s_copy, hipStreamNonBlocking) == hipSuccess &&
+                 hipStreamCreateWithFlags(&u->s_xpose, hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 2 && ok; ++i) {
+                ok = hipEventCreateWithFlags(&u->copied[i], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&u->freed[i], hipEventDisableTiming) == hipSuccess &&
+                     hipMalloc(reinterpret_cast<void**>(&u->staging[i]), need) == hipSuccess;
+            }
+            u->staging_bytes = need;
         }
+        u->chunk_cols = cc;
+        u->rc = BH_OK;
         if (!ok) {
-            async_upload_cleanup(u);
-            delete u;
-            H->up = nullptr;
+            async_upload_destroy(u);
             rc = fail(BH_ERR_HIP, "bh_hess_create_async: streams / events / staging buffers");
         } else {
+            H->up = u;
             u->worker = std::thread(async_upload_worker, H, J, d, n, ldJ, g_ctx.device);
         }
     } else if (rc == BH_OK) {
@@ -1388,7 +1423,6 @@ int32_t bh_hess_destroy(bh_hess* H) {
         AsyncUpload* u = H->up;
         if (u->worker.joinable()) u->worker.join();
         async_upload_cleanup(u);
-        delete u;
         H->up = nullptr;
     }
     if (H->counted) g_ctx.live_hess -= 1;
@@ -1477,6 +1511,9 @@ int32_t bh_proj_create(bh_proj** out, const double* A, int64_t mA, int64_t n, in
     int32_t rc = dev_alloc(&P->Ad, std::max<int64_t>(mA, 1) * P->ldA);
     if (rc == BH_OK) rc = dev_alloc(&P->fixrank, P->ldA);
     if (rc == BH_OK) rc = dev_alloc(&P->fixidx, n);
+    if (rc == BH_OK) rc = dev_alloc(&P->newidx, n);
+    if (rc == BH_OK) rc = dev_alloc(&P->counts, 8);
+    if (rc == BH_OK) rc = dev_alloc(&P->chunks_dev, (n + 63) / 64 + 1);
     if (rc == BH_OK) rc = dev_alloc(&P->tw, n + 16);
     if (rc == BH_OK) rc = dev_alloc(&P->rpad, P->ldA);
     if (rc == BH_OK) rc = dev_alloc(&P->vtmp, P->ldA);
@@ -1523,6 +1560,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
                     BH_TRY(dev_alloc(&P->L, mpp * mpp));
                     P->L_cap = mpp * mpp;
                 }
+                count_h2d((size_t)mpp * mpp * sizeof(double));
                 BH_HIP(hipMemcpy2DAsync(P->L, (size_t)mpp * sizeof(double), L, (size_t)ldL * sizeof(double), (size_t)mpp * sizeof(double),
                                         (size_t)mpp, hipMemcpyHostToDevice, g_ctx.stream));
                 P->have_L = true;
@@ -1534,6 +1572,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     } else if (mpp != want && L != nullptr) {
         return fail(BH_ERR_SHAPE, "mpp != count(fixvars) for mA == 0");
     }
+    count_h2d((size_t)(P->ldA + nfix) * sizeof(int));
     BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
     if (nfix > 0) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), (size_t)nfix * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
     P->nfix = nfix; P->mpp = (int)want; P->reduced = reduced;
@@ -1564,6 +1603,7 @@ int32_t bh_proj_destroy(bh_proj* P) {
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
     dev_free(P->Lr); dev_free(P->M); dev_free(P->info);
+    dev_free(P->newidx); dev_free(P->counts); dev_free(P->chunks_dev);
     delete P;
     return BH_OK;
 }
@@ -1793,6 +1833,7 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     PcgFin fin{};
     BH_TRY(pcg_run(H, P, gp, wlp, wup, wp, !in_place, kappa2, atol_negcurv, atol_f2b, trace_cap, &fin));
     if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
+    if (trace_cap > 0) count_d2h((size_t)4 * trace_cap * sizeof(double));
     if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
     BH_TRY(sync_flush());      // drains the over-launched no-op kernels; orders w for any consumer
     BH_TRY(pcg_finish(H, fin));
@@ -1844,8 +1885,8 @@ static int32_t launch_linesearch(bh_hess* H, bh_proj* P, const double* g_dev, do
     return BH_OK;
 }
 
-int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const double* w, const double* w_l, const double* w_u,
-                      double* alpha_out) {
+static int32_t linesearch_impl(bh_hess* H, bh_proj* P, const double* g_model, const double* w, const double* w_l, const double* w_u,
+                               double* alpha_out, bool dev) {
     BH_REQUIRE_INIT();
     if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
     BH_TRY(check_proj_ready(P));
@@ -1855,21 +1896,29 @@ int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const doubl
     BH_TRY(ensure_cg_workspace(H->ld, 0));
     CgWorkspace& c = g_ctx.cg;
     BH_HIP(hipMemsetAsync(c.w, 0, (size_t)H->ld * sizeof(double), g_ctx.stream));
-    BH_TRY(stage_vec(c.w, w, n, false));
-    BH_TRY(stage_vec(c.g, g_model, n, false));
-    BH_TRY(stage_vec(c.wl, w_l, n, false));
-    BH_TRY(stage_vec(c.wu, w_u, n, false));
+    BH_TRY(stage_vec(c.w, w, n, dev));
+    BH_TRY(stage_vec(c.g, g_model, n, dev));
+    BH_TRY(stage_vec(c.wl, w_l, n, dev));
+    BH_TRY(stage_vec(c.wu, w_u, n, dev));
     BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, false));
     BH_TRY(fetch_vec(alpha_out, c.scalars, 1, false));
     BH_TRY(sync_flush());
     return BH_OK;
 }
+int32_t bh_linesearch(bh_hess* H, bh_proj* P, const double* g_model, const double* w, const double* w_l, const double* w_u,
+                      double* alpha_out) {
+    return linesearch_impl(H, P, g_model, w, w_l, w_u, alpha_out, false);
+}
+int32_t bh_linesearch_dev(bh_hess* H, bh_proj* P, const double* g_model_dev, const double* w_dev, const double* w_l_dev,
+                          const double* w_u_dev, double* alpha_out) {
+    return linesearch_impl(H, P, g_model_dev, w_dev, w_l_dev, w_u_dev, alpha_out, true);
+}
 
 // minor_iterate(x, s, g_model, H, lincons, delta, kappa2) — src/basic_tralcnlss.jl:649-675, entirely on the device:
 // step bounds (:660-665), projected_cg (:667), linesearch + scaling (:669-672).
-int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* s_vec, const double* g_model, const double* xlow,
-                         const double* xupp, double delta, double kappa2, double atol_negcurv, double atol_f2b, double* w_out,
-                         int32_t* status, int32_t* iters, int32_t* n_hmul_out, double* alpha_out) {
+static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const double* s_vec, const double* g_model, const double* xlow,
+                                  const double* xupp, double delta, double kappa2, double atol_negcurv, double atol_f2b, double* w_out,
+                                  int32_t* status, int32_t* iters, int32_t* n_hmul_out, double* alpha_out, bool dev) {
     BH_REQUIRE_INIT();
     if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
     BH_TRY(check_proj_ready(P));
@@ -1878,13 +1927,19 @@ int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* 
     const int64_t n = H->n;
     BH_TRY(ensure_cg_workspace(H->ld, 0));
     CgWorkspace& c = g_ctx.cg;
-    BH_TRY(stage_vec(c.x, x, n, false));
-    BH_TRY(stage_vec(c.s, s_vec, n, false));
-    BH_TRY(stage_vec(c.g, g_model, n, false));
-    BH_TRY(stage_vec(c.xlow, xlow, n, false));
-    BH_TRY(stage_vec(c.xupp, xupp, n, false));
+    // device callers: x, s and the bounds are only read element-wise (no staging); g_minor is copied device-to-device into
+    // the zero-padded workspace vector the CG kernels read in 16-byte chunks
+    const double *xp = x, *sp = s_vec, *lop = xlow, *upp = xupp;
+    if (!dev) {
+        BH_TRY(stage_vec(c.x, x, n, false));
+        BH_TRY(stage_vec(c.s, s_vec, n, false));
+        BH_TRY(stage_vec(c.xlow, xlow, n, false));
+        BH_TRY(stage_vec(c.xupp, xupp, n, false));
+        xp = c.x; sp = c.s; lop = c.xlow; upp = c.xupp;
+    }
+    BH_TRY(stage_vec(c.g, g_model, n, dev));
     const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
-    hipLaunchKernelGGL(step_bounds_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, c.x, c.s, c.xlow, c.xupp,
+    hipLaunchKernelGGL(step_bounds_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, xp, sp, lop, upp,
                        P->nfix > 0 ? P->fixrank : (const int*)nullptr, delta, (int)n, c.wl, c.wu);
     PcgFin fin{};
     // ls_from_cg: the CG loop accumulates H*w next to w, so linesearch's w'Hw (vthv(H,w), :775) costs a dot product
@@ -1897,7 +1952,7 @@ int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* 
         BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, true, hw));
         BH_TRY(fetch_vec(&alpha, c.scalars, 1, false));
     }
-    BH_TRY(fetch_vec(w_out, c.w, n, false));
+    BH_TRY(fetch_vec(w_out, c.w, n, dev));
     BH_TRY(sync_flush());
     BH_TRY(pcg_finish(H, fin));
     if (status) *status = fin.status;
@@ -1907,18 +1962,35 @@ int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* 
     return BH_OK;
 }
 
+int32_t bh_minor_iterate(bh_hess* H, bh_proj* P, const double* x, const double* s_vec, const double* g_model, const double* xlow,
+                         const double* xupp, double delta, double kappa2, double atol_negcurv, double atol_f2b, double* w_out,
+                         int32_t* status, int32_t* iters, int32_t* n_hmul_out, double* alpha_out) {
+    return minor_iterate_impl(H, P, x, s_vec, g_model, xlow, xupp, delta, kappa2, atol_negcurv, atol_f2b, w_out, status, iters, n_hmul_out,
+                              alpha_out, false);
+}
+int32_t bh_minor_iterate_dev(bh_hess* H, bh_proj* P, const double* x_dev, const double* s_dev, const double* g_model_dev,
+                             const double* xlow_dev, const double* xupp_dev, double delta, double kappa2, double atol_negcurv,
+                             double atol_f2b, double* w_out_dev, int32_t* status, int32_t* iters, int32_t* n_hmul_out, double* alpha_out) {
+    return minor_iterate_impl(H, P, x_dev, s_dev, g_model_dev, xlow_dev, xupp_dev, delta, kappa2, atol_negcurv, atol_f2b, w_out_dev, status,
+                              iters, n_hmul_out, alpha_out, true);
+}
+
 // g = Jx'*rx + Cx'*y_bar — src/basic_tralcnlss.jl:45,:74 (r = this rank's d rows; C'y_bar added by rank 0; all-reduced).
-int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out) {
+static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info_out);
+
+static int32_t grad_impl(bh_hess* H, const double* r, const double* ybar, double* g_out, bool dev) {
     BH_REQUIRE_INIT();
     if (!H || (!r && H->d > 0) || (!ybar && H->q > 0) || !g_out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
-    BH_TRY(stage_vec(H->upad, r, H->d, false));
-    BH_TRY(stage_vec(H->upad + H->d, ybar, H->q, false));
+    BH_TRY(stage_vec(H->upad, r, H->d, dev));
+    BH_TRY(stage_vec(H->upad + H->d, ybar, H->q, false));         // q multipliers: always a (tiny) host vector
     BH_TRY(launch_jtv(H, H->upad, H->zpad, true));
-    BH_TRY(fetch_vec(g_out, H->zpad, H->n, false));
+    BH_TRY(fetch_vec(g_out, H->zpad, H->n, dev));
     BH_TRY(sync_flush());
     H->stats.n_jtv += 1;
     return BH_OK;
 }
+int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out) { return grad_impl(H, r, ybar, g_out, false); }
+int32_t bh_grad_dev(bh_hess* H, const double* r_dev, const double* ybar, double* g_out_dev) { return grad_impl(H, r_dev, ybar, g_out_dev, true); }
 
 // dot(rx, rx) of mx = 0.5*dot(rx,rx) + ... — src/basic_tralcnlss.jl:44 (new_point), :58 (evaluate_al): r = this rank's rows of
 // the residual; the partial sums of squares are all-reduced (rank order), so every rank gets the same bits.
@@ -1942,29 +2014,149 @@ int32_t bh_resid_sqnorm(const double* r, int64_t d, double* out) {
 }
 
 // g_minor = H*s + g — src/basic_tralcnlss.jl:412,:437.
-int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* out_n) {
+static int32_t hmul_add_impl(bh_hess* H, const double* s_vec, const double* g, double* out_n, bool dev, const double* w_add = nullptr,
+                             double* s_inout = nullptr) {
     BH_REQUIRE_INIT();
     if (!H || !s_vec || !g || !out_n) return fail(BH_ERR_INVALID_ARG, "NULL argument");
     const int64_t n = H->n;
     BH_TRY(ensure_cg_workspace(H->ld, 0));
-    CgWorkspace& c = g_ctx.cg;
-    BH_TRY(stage_vec(H->vpad, s_vec, n, false));
-    BH_TRY(stage_vec(c.g, g, n, false));
-    BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
     const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
-    hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, (const double*)c.g, H->zpad, (int)n);
-    BH_TRY(fetch_vec(out_n, H->zpad, n, false));
+    if (w_add != nullptr)      // s .+= w (:436) on the caller's device vector, then H*s + g
+        hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)s_inout, w_add, s_inout, (int)n);
+    BH_TRY(stage_vec(H->vpad, s_vec, n, dev));
+    BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
+    if (dev) {
+        hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, g, out_n, (int)n);
+        BH_HIP(hipGetLastError());
+    } else {
+        CgWorkspace& c = g_ctx.cg;
+        BH_TRY(stage_vec(c.g, g, n, false));
+        hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, (const double*)c.g, H->zpad, (int)n);
+        BH_TRY(fetch_vec(out_n, H->zpad, n, false));
+    }
     BH_TRY(sync_flush());
     H->stats.n_hmul += 1;
     return BH_OK;
 }
+int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* out_n) { return hmul_add_impl(H, s_vec, g, out_n, false); }
+int32_t bh_hmul_add_dev(bh_hess* H, const double* s_dev, const double* g_dev, double* out_n_dev) {
+    return hmul_add_impl(H, s_dev, g_dev, out_n_dev, true);
+}
+// s .+= w ; g_minor = H*s + g — src/basic_tralcnlss.jl:436-437, on device vectors (s is updated in place).
+int32_t bh_step_accumulate_dev(bh_hess* H, double* s_dev, const double* w_dev, const double* g_dev, double* g_minor_out_dev) {
+    if (!w_dev || !s_dev) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    return hmul_add_impl(H, s_dev, g_dev, g_minor_out_dev, true, w_dev, s_dev);
+}
 
-// Shared by bh_proj_set_active and bh_cauchy_step: make the host bookkeeping and the canonical device arrays
-// (fixrank = rank among fixed, fixidx) match `mask` (n entries, nonzero = fixed).
-static int32_t adopt_mask(bh_proj* P, const std::vector<int>& rank, const std::vector<int>& idx) {
-    BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
-    if (!idx.empty()) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+// active_indx = active_bounds(lincons, x, s, delta); add_active!(lincons, chol_aat, active_indx) — or, when mA + |active_indx| > n,
+// active_bounds!(lincons, x+s, chol_aat) — src/basic_tralcnlss.jl:439-453, src/polyhedral_constraints.jl:203-261, on the device:
+// the active set lives in HBM, newly fixed variables are taken out of A_free A_free' by a Gram DOWNDATE over just their
+// columns (then the mA x mA refactorisation) instead of the reference's from-scratch O(p^3) cholesky_aug_aat rebuild; only
+// three counts come back.
+int32_t bh_proj_update_active_dev(bh_proj* P, const double* x_dev, const double* s_dev, const double* xlow_dev, const double* xupp_dev,
+                                  double delta, double atol, int32_t* n_at_bound, int32_t* n_fixed, int32_t* branch, uint64_t* fix_chunks_out) {
+    BH_REQUIRE_INIT();
+    if (!P || !x_dev || !s_dev || !xlow_dev || !xupp_dev) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    if (P->mA > 0 && g_ctx.opt_proj_form == 0)
+        return fail(BH_ERR_UNSUPPORTED, "bh_proj_update_active_dev needs the reduced projection form (proj_form = 1)");
+    const int mA = (int)P->mA;
+    hipStream_t s = g_ctx.stream;
+    if (mA > 0) {
+        BH_TRY(ensure_reduced_buffers(P));
+        const size_t lds = trsv_lds_bytes(mA);
+        if (lds > kLdsPerCu) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
+        BH_TRY(ensure_trsv_lds(lds));
+    }
+    const bool had_factor = P->active_set && P->reduced && P->M_valid;   // M and Lr describe the CURRENT active set: a downdate is enough
+    hipLaunchKernelGGL(active_update_kernel, dim3(1), dim3(CG_T), 0, s, x_dev, s_dev, xlow_dev, xupp_dev, delta, atol, (int)P->n, (int)P->ldA,
+                       mA, P->fixrank, P->newidx, P->counts);
+    BH_HIP(hipGetLastError());
+    int counts[4] = {0, 0, 0, 0};
+    count_d2h(sizeof(counts));
+    BH_HIP(hipMemcpyAsync(counts, P->counts, sizeof(counts), hipMemcpyDeviceToHost, s));
     BH_TRY(sync_flush());
+    if (mA > 0) {
+        if (counts[AU_BRANCH] == 0 && had_factor) {
+            if (counts[AU_NEW] > 0) {
+                hipLaunchKernelGGL(gram_downdate_list_kernel, dim3(std::max(1, std::min(1024, (mA * mA + 255) / 256))), dim3(256), 0, s, P->M,
+                                   (const double*)P->Ad, P->ldA, mA, (const int*)P->newidx, (const int*)P->counts);
+                BH_TRY(launch_chol(P, nullptr));
+            }
+        } else {
+            BH_TRY(launch_reduced_factor(P, true, nullptr));      // active set replaced (or no factor yet): from the mask
+        }
+    }
+    P->active_set = false;
+    int info_host = 0;
+    BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host));
+    if (info_host != 0) {
+        P->active_set = false;
+        return fail(BH_ERR_PRECONDITION, "A_free*A_free' is not positive definite (PosDefException in the reference's cholesky)");
+    }
+    if (n_at_bound) *n_at_bound = counts[AU_AT_BOUND];
+    if (n_fixed) *n_fixed = P->nfix;
+    if (branch) *branch = counts[AU_BRANCH];
+    return BH_OK;
+}
+
+// norm_reduced_gradient(g, lincons) = norm(projection(lincons, -g)) — src/basic_tralcnlss.jl:869-875 (criticality_measure :839).
+// The projector is linear and every operation in it is sign-symmetric in IEEE arithmetic, so ||P(-g)|| and ||P(g)|| are the
+// same bits: g is projected as it is.
+int32_t bh_reduced_gradient_norm_dev(bh_proj* P, const double* g_dev, double* out) {
+    BH_REQUIRE_INIT();
+    BH_TRY(check_proj_ready(P));
+    if (!g_dev || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(stage_vec(P->rpad, g_dev, P->n, true));
+    BH_TRY(launch_project(P, P->rpad, P->vtmp, nullptr));
+    hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, (const double*)P->vtmp, (int)P->n, P->tw);
+    BH_HIP(hipGetLastError());
+    BH_TRY(fetch_vec(out, P->tw, 1, false));
+    BH_TRY(sync_flush());
+    return BH_OK;
+}
+
+// model_reduction = dot(g,s) + 0.5*vthv(H,s) — src/basic_tralcnlss.jl:458.
+int32_t bh_model_reduction_dev(bh_hess* H, const double* g_dev, const double* s_dev, double* out) {
+    BH_REQUIRE_INIT();
+    if (!H || !g_dev || !s_dev || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    BH_TRY(ensure_cg_workspace(H->ld, 0));
+    CgWorkspace& c = g_ctx.cg;
+    BH_TRY(stage_vec(H->vpad, s_dev, H->n, true));
+    BH_TRY(launch_jv(H, H->vpad, nullptr, true, H->scalar));
+    BH_TRY(allreduce_inplace(H->scalar, 1, H));
+    hipLaunchKernelGGL(vec_dot_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, g_dev, s_dev, (int)H->n, c.scalars + 1);
+    BH_HIP(hipGetLastError());
+    double vals[2] = {0.0, 0.0};
+    BH_TRY(fetch_vec(&vals[0], H->scalar, 1, false));
+    BH_TRY(fetch_vec(&vals[1], c.scalars + 1, 1, false));
+    BH_TRY(sync_flush());
+    H->stats.n_jv += 1;
+    *out = vals[1] + 0.5 * vals[0];
+    return BH_OK;
+}
+
+// After the device-side active set (P->fixrank >= 0 <=> fixed) has changed — bh_cauchy_step, bh_proj_update_active_dev —
+// bring the canonical device arrays (fixrank = rank among the fixed, fixidx) and the host bookkeeping in line with it
+// WITHOUT moving the mask through the host: a scan kernel renumbers in place, and only the count, the BitVector image
+// (n/8 bytes: what the caller's lincons.fixvars needs) and the factorisation flag come back.
+static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info_out) {
+    const int64_t n = P->n;
+    const size_t nwords = (size_t)((n + 63) / 64);
+    hipLaunchKernelGGL(canon_mask_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->fixrank, P->fixidx, (int)n, (int)P->ldA, P->chunks_dev, P->counts);
+    BH_HIP(hipGetLastError());
+    std::vector<uint64_t> chunks(nwords, 0ull);
+    int counts[4] = {0, 0, 0, 0};
+    int info_host = 0;
+    count_d2h(nwords * sizeof(uint64_t) + sizeof(counts) + sizeof(int));
+    BH_HIP(hipMemcpyAsync(chunks.data(), P->chunks_dev, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost, g_ctx.stream));
+    BH_HIP(hipMemcpyAsync(counts, P->counts, sizeof(counts), hipMemcpyDeviceToHost, g_ctx.stream));
+    if (P->mA > 0 && P->info) BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+    BH_TRY(sync_flush());
+    P->nfix = counts[AU_FIXED]; P->mpp = (int)P->mA + P->nfix; P->reduced = P->mA > 0; P->have_L = false;
+    P->last_chunks = chunks;
+    P->active_set = true;
+    if (fix_chunks_out) memcpy(fix_chunks_out, chunks.data(), nwords * sizeof(uint64_t));
+    if (info_out) *info_out = info_host;
     return BH_OK;
 }
 
@@ -1972,8 +2164,8 @@ static int32_t adopt_mask(bh_proj* P, const std::vector<int>& rank, const std::v
 // active_bounds! (poly:203-215), projection of -g, then per breakpoint one H*d, one projection and — instead of the
 // reference's O(p^3) host refactorisation (add_active! -> cholesky_aug_aat) — a rank-one downdate of A_free A_free' and an
 // mA x mA Cholesky on the device.  On return lincons' active set is the one the reference would hold (fix_chunks_out).
-int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g, const double* xlow, const double* xupp, double delta,
-                       double* s_out, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul_out) {
+static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double* g, const double* xlow, const double* xupp, double delta,
+                           double* s_out, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul_out, bool dev) {
     BH_REQUIRE_INIT();
     if (!H || !P) return fail(BH_ERR_INVALID_ARG, "NULL handle");
     if (!x || !g || !xlow || !xupp || !s_out) return fail(BH_ERR_INVALID_ARG, "NULL vector argument");
@@ -1991,10 +2183,10 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
         if (lds > kLdsPerCu) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
         BH_TRY(ensure_trsv_lds(lds));
     }
-    BH_TRY(stage_vec(c.x, x, n, false));
-    BH_TRY(stage_vec(c.g, g, n, false));
-    BH_TRY(stage_vec(c.xlow, xlow, n, false));
-    BH_TRY(stage_vec(c.xupp, xupp, n, false));
+    BH_TRY(stage_vec(c.x, x, n, dev));
+    BH_TRY(stage_vec(c.g, g, n, dev));
+    BH_TRY(stage_vec(c.xlow, xlow, n, dev));
+    BH_TRY(stage_vec(c.xupp, xupp, n, dev));
 
     CauchyArgs a{};
     a.st = c.d_state; a.x = c.x; a.g = c.g; a.xlow = c.xlow; a.xupp = c.xupp;
@@ -2015,6 +2207,7 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     auto launch_pass = [&](int index) -> int32_t {
         if (index > 0 && mA > 0) {
             if (g_ctx.opt_chol_downdate) {
+                P->M_valid = false;     // only the factor follows the active set on this path
                 // add_active!: one more fixed variable = rank-one downdate of chol(A_free A_free'), O(mA^2)
                 if (mA <= 64)
                     hipLaunchKernelGGL(chol_downdate_small_kernel, dim3(1), dim3(64), 0, s, P->Lr, (const double*)P->Ad, P->ldA, mA, P->info,
@@ -2055,25 +2248,11 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
         if (done_by(target) || !more) break;
     }
     BH_TRY(wait_mirror(c, a.tag, launched, &mw));
-    std::vector<int> mask((size_t)P->ldA, -1);
-    BH_TRY(fetch_vec(s_out, c.w, n, false));
-    BH_HIP(hipMemcpyAsync(mask.data(), P->fixrank, (size_t)P->ldA * sizeof(int), hipMemcpyDeviceToHost, s));
+    BH_TRY(fetch_vec(s_out, c.w, n, dev));
     int info_host = 0;
-    if (mA > 0) BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, s));
-    BH_TRY(sync_flush());
+    BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host));     // drains the stream; canonical fixrank / fixidx, P->nfix
     H->stats.n_hmul += mw.n_hmul;
     if (!mw.done) return fail(BH_ERR_HIP, "internal: Cauchy loop did not terminate");
-    // canonical bookkeeping for the final active set
-    std::vector<int> rank((size_t)P->ldA, -1), idx;
-    const size_t nwords = (size_t)((n + 63) / 64);
-    std::vector<uint64_t> chunks(nwords, 0ull);
-    for (int64_t i = 0; i < n; ++i)
-        if (mask[(size_t)i] >= 0) { rank[(size_t)i] = (int)idx.size(); idx.push_back((int)i); chunks[(size_t)(i >> 6)] |= 1ull << (i & 63); }
-    BH_TRY(adopt_mask(P, rank, idx));
-    P->nfix = (int)idx.size(); P->mpp = mA + P->nfix; P->reduced = mA > 0; P->have_L = false;
-    P->last_chunks = chunks;
-    P->active_set = true;
-    if (fix_chunks_out) memcpy(fix_chunks_out, chunks.data(), nwords * sizeof(uint64_t));
     if (n_breakpoints) *n_breakpoints = mw.iter;
     if (n_hmul_out) *n_hmul_out = mw.n_hmul;
     if (mw.status != 0)
@@ -2081,6 +2260,15 @@ int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g,
     if (info_host != 0)
         return fail(BH_ERR_PRECONDITION, "cauchy_step: A_free*A_free' lost positive definiteness (PosDefException in the reference)");
     return BH_OK;
+}
+
+int32_t bh_cauchy_step(bh_hess* H, bh_proj* P, const double* x, const double* g, const double* xlow, const double* xupp, double delta,
+                       double* s_out, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul_out) {
+    return cauchy_impl(H, P, x, g, xlow, xupp, delta, s_out, fix_chunks_out, n_breakpoints, n_hmul_out, false);
+}
+int32_t bh_cauchy_step_dev(bh_hess* H, bh_proj* P, const double* x_dev, const double* g_dev, const double* xlow_dev, const double* xupp_dev,
+                           double delta, double* s_out_dev, uint64_t* fix_chunks_out, int32_t* n_breakpoints, int32_t* n_hmul_out) {
+    return cauchy_impl(H, P, x_dev, g_dev, xlow_dev, xupp_dev, delta, s_out_dev, fix_chunks_out, n_breakpoints, n_hmul_out, true);
 }
 
 int32_t bh_factor_to_boundary(const double* p, const double* w, const double* w_l, const double* w_u, int64_t n, double atol,
@@ -2113,12 +2301,14 @@ int32_t bh_dev_alloc(void** out, int64_t bytes) {
 int32_t bh_dev_free(void* p) { dev_free(p); return BH_OK; }
 int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
     BH_REQUIRE_INIT();
+    count_h2d((size_t)bytes);
     BH_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, g_ctx.stream));
     BH_TRY(sync_flush());
     return BH_OK;
 }
 int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
     BH_REQUIRE_INIT();
+    count_d2h((size_t)bytes);
     BH_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     BH_TRY(sync_flush());
     return BH_OK;
@@ -2127,6 +2317,8 @@ int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
 int32_t bh_stats(bh_hess* H, bh_stats_t* out) {
     if (!H || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
     *out = H->stats;
+    out->h2d_bytes = g_ctx.h2d_bytes; out->d2h_bytes = g_ctx.d2h_bytes;       // library-wide, since bh_init
+    out->h2d_calls = g_ctx.h2d_calls; out->d2h_calls = g_ctx.d2h_calls;
     return BH_OK;
 }
 int32_t bh_stats_reset(bh_hess* H) {

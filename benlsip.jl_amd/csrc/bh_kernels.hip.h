@@ -22,3 +22,4 @@
 #include "bh_proj.hip.h"
 #include "bh_cauchy.hip.h"
 #include "bh_comm.hip.h"
+#include "bh_minor.hip.h"

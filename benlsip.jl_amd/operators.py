@@ -460,6 +460,90 @@ def hmul_add(H, s, g):
     return out
 
 
+def transfer_counters():
+    """Library-wide host<->device traffic since ``bh_init`` (``bh_stats``): (h2d_bytes, d2h_bytes, h2d_calls, d2h_calls)."""
+    st = _lib.bh_stats_t()
+    h = _null_handle()
+    # any live handle reports the library-wide counters; a throw-away 1x1 image serves when the caller has none at hand
+    H = AlHessian(np.zeros((1, 1)), None, 0.0)
+    try:
+        check(_lib.lib().bh_stats(H.handle, ct.byref(st)), "bh_stats")
+    finally:
+        H.close()
+    return st.h2d_bytes, st.d2h_bytes, st.h2d_calls, st.d2h_calls
+
+
+def _xfer(H):
+    st = _lib.bh_stats_t()
+    check(_lib.lib().bh_stats(H.handle, ct.byref(st)), "bh_stats")
+    return st.h2d_bytes + st.d2h_bytes
+
+
+def inner_step(x, g, H, lincons, delta, nb_minor_step, kappa2, kappa3, atol=SQRT_EPS, atol_f2b=1e-10, full_output=False):
+    """``inner_step(x, g, H, chol_aat, lincons, delta, nb_minor_step, kappa2, kappa3)`` — src/basic_tralcnlss.jl:394-460 — with
+    every n-vector of the minor loop resident in HBM: x, g and the bounds go up once, the Cauchy search,
+    the minor iterates, ``s .+= w``, ``H*s+g``, the active-set growth (device-side ``active_bounds`` + Gram downdate instead
+    of the reference's factor rebuild) and the reduced-gradient norms all work on device vectors, and ``s`` comes down once.
+    Returns ``(s, model_reduction)`` and leaves ``lincons.fixvars`` as the reference's method does.  This is the executable
+    mirror of the ``BEnlsip.inner_step`` method in julia/BEnlsipHIP.jl."""
+    lib = _lib.lib()
+    n, mA = H.n, lincons.mA
+    x, g = as_f64(x, n), as_f64(g, n)
+    dv = getattr(lincons, "_resident", None)
+    if dv is None:
+        dv = {k: DeviceVector(n) for k in ("x", "g", "s", "w", "gm")}
+        dv["xlow"], dv["xupp"] = DeviceVector(n, lincons.xlow), DeviceVector(n, lincons.xupp)
+        lincons._resident = dv
+    dv["x"].upload(x)
+    dv["g"].upload(g)
+    lincons._sync()
+    P = lincons._h
+    nwords = (n + 63) // 64
+    chunks = np.zeros(nwords, dtype=np.uint64)
+    nbp, nh = ct.c_int32(0), ct.c_int32(0)
+    t0 = _xfer(H)
+    check(lib.bh_cauchy_step_dev(H.handle, P, dv["x"].ptr, dv["g"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta), dv["s"].ptr,
+                                 ptr(chunks), ct.byref(nbp), ct.byref(nh)), "bh_cauchy_step_dev")            # :410
+    check(lib.bh_hmul_add_dev(H.handle, dv["s"].ptr, dv["g"].ptr, dv["gm"].ptr), "bh_hmul_add_dev")          # :412
+    nfix = int(np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].sum())
+
+    def red_norm(vec):
+        out = ct.c_double(0.0)
+        check(lib.bh_reduced_gradient_norm_dev(P, vec.ptr, ct.byref(out)), "bh_reduced_gradient_norm_dev")
+        return out.value
+    nrg, nrgm = red_norm(dv["g"]), red_norm(dv["gm"])                                                        # :420-421
+    approx_solved = nrgm <= kappa3 * nrg
+    max_minor_step = min(nb_minor_step, n - mA - nfix)                                                       # :425-426
+    j, cg_stop, statuses = 1, False, []
+    while j <= max_minor_step and not approx_solved and not cg_stop:                                         # :430
+        status, iters, n_hmul, alpha = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0), ct.c_double(0.0)
+        check(lib.bh_minor_iterate_dev(H.handle, P, dv["x"].ptr, dv["s"].ptr, dv["gm"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta),
+                                       float(kappa2), float(atol), float(atol_f2b), dv["w"].ptr, ct.byref(status), ct.byref(iters),
+                                       ct.byref(n_hmul), ct.byref(alpha)), "bh_minor_iterate_dev")           # :434
+        cg_stop = status.value == int(CGStatus.negative_curvature)
+        check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["gm"].ptr), "bh_step_accumulate_dev")   # :436-437
+        n_at, n_fixed, branch = ct.c_int32(0), ct.c_int32(0), ct.c_int32(0)
+        check(lib.bh_proj_update_active_dev(P, dv["x"].ptr, dv["s"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta), float(atol),
+                                            ct.byref(n_at), ct.byref(n_fixed), ct.byref(branch), ptr(chunks)), "bh_proj_update_active_dev")   # :439-453
+        if branch.value == 0:
+            nrg, nrgm = red_norm(dv["g"]), red_norm(dv["gm"])                                                # :446-447
+            approx_solved = nrgm <= kappa3 * nrg
+        else:
+            approx_solved = True
+        statuses.append((CGStatus(status.value), iters.value, n_fixed.value, nrgm / (kappa3 * nrg) if nrg > 0 else math.inf))
+        j += 1
+    mr = ct.c_double(0.0)
+    check(lib.bh_model_reduction_dev(H.handle, dv["g"].ptr, dv["s"].ptr, ct.byref(mr)), "bh_model_reduction_dev")   # :458
+    loop_bytes = _xfer(H) - t0
+    s = dv["s"].download()
+    lincons._fixvars = np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].astype(bool)
+    lincons._chol = None
+    lincons._dirty = False              # the device already holds this active set
+    if full_output:
+        return s, mr.value, {"minor": statuses, "n_breakpoints": nbp.value, "pcie_bytes_in_loop": int(loop_bytes)}
+    return s, mr.value
+
+
 class DeviceVector:
     """A float64 vector resident in HBM (plumbing for the ``*_dev`` entry points)."""
 

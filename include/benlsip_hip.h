@@ -71,6 +71,10 @@ typedef struct bh_stats_t {
     double  hmul_ms;         /* sum of hipEvent durations of the H*p kernel (BH_FLAG_PROFILE) */
     int64_t hmul_timed;      /* number of H*p launches contributing to hmul_ms           */
     double  bytes_per_hmul;  /* algorithmic bytes of one H*p launch on this rank (8*(d+q)*n + 16*n) */
+    /* library-wide (all handles), since bh_init: host <-> device copies the library has issued — vectors staged for the
+     * host-pointer entry points, masks, factors, traces, J uploads; 8-byte scalars coming back through pinned memory are
+     * included.  The *_dev entry points move none of the n-vectors they work on (tests check the difference of these counters). */
+    int64_t h2d_bytes, d2h_bytes, h2d_calls, d2h_calls;
 } bh_stats_t;
 
 /* ---- library / device --------------------------------------------------- */
@@ -233,6 +237,41 @@ int32_t bh_grad(bh_hess* H, const double* r, const double* ybar, double* g_out);
 int32_t bh_resid_sqnorm(const double* r, int64_t d, double* out);
 /* g_minor = H*s + g — src/basic_tralcnlss.jl:412,:437. */
 int32_t bh_hmul_add(bh_hess* H, const double* s, const double* g, double* out_n);
+
+/* ---- the minor loop of inner_step with its vectors resident in HBM --------------------------------
+ * src/basic_tralcnlss.jl:410-458: s = cauchy_step(...); g_minor = H*s+g; while ...: w = minor_iterate(...); s .+= w;
+ * g_minor = H*s+g; active_bounds / add_active!; norm_reduced_gradient x 2; ...; model_reduction.  Every *_dev entry point takes
+ * and returns DEVICE pointers for the n-vectors (x, s, g, g_minor, w, xlow, xupp); only scalars, counts and the n/8-byte
+ * BitVector image of the active set cross PCIe (bh_stats' h2d/d2h counters let a caller check that).  A caller that owns the
+ * loop (julia/BEnlsipHIP.jl's inner_step method; tests/hip_ops.py::DeviceResidentInnerStep) uploads x, g and the bounds once
+ * per trust-region iteration and downloads s once. */
+int32_t bh_cauchy_step_dev(bh_hess* H, bh_proj* P, const double* x_dev, const double* g_dev, const double* xlow_dev,
+                           const double* xupp_dev, double delta, double* s_out_dev, uint64_t* fix_chunks_out /* host, optional */,
+                           int32_t* n_breakpoints, int32_t* n_hmul);
+int32_t bh_minor_iterate_dev(bh_hess* H, bh_proj* P, const double* x_dev, const double* s_dev, const double* g_model_dev,
+                             const double* xlow_dev, const double* xupp_dev, double delta, double kappa2, double atol_negcurv,
+                             double atol_f2b, double* w_out_dev, int32_t* status, int32_t* iters, int32_t* n_hmul, double* alpha_out);
+int32_t bh_linesearch_dev(bh_hess* H, bh_proj* P, const double* g_model_dev, const double* w_dev, const double* w_l_dev,
+                          const double* w_u_dev, double* alpha_out);
+/* r_dev = this rank's d residual rows in HBM (a device-side residual callback); y_bar (q entries) stays a host vector. */
+int32_t bh_grad_dev(bh_hess* H, const double* r_dev, const double* ybar, double* g_out_dev);
+int32_t bh_hmul_add_dev(bh_hess* H, const double* s_dev, const double* g_dev, double* out_n_dev);
+/* s .+= w ; g_minor = H*s + g — src/basic_tralcnlss.jl:436-437 (s_dev is updated in place). */
+int32_t bh_step_accumulate_dev(bh_hess* H, double* s_dev, const double* w_dev, const double* g_dev, double* g_minor_out_dev);
+/* src/basic_tralcnlss.jl:439-453 on the device-side active set:
+ *     active_indx = active_bounds(lincons, x, s, delta)                      src/polyhedral_constraints.jl:219-237 (atol = sqrt(eps))
+ *     if mA + |active_indx| <= n:  add_active!(lincons, chol_aat, active_indx)    poly:252-261      -> *branch = 0
+ *     else:                        active_bounds!(lincons, x+s, chol_aat)         poly:203-215      -> *branch = 1
+ * Newly fixed variables leave A_free A_free' through a Gram DOWNDATE over their columns followed by the mA x mA factorisation
+ * (the reference rebuilds the (mA+p) x (mA+p) augmented factor from scratch, O(p^3)).  n_at_bound = |active_indx|,
+ * n_fixed = count(fixvars) afterwards; fix_chunks_out (host, optional, ceil(n/64) words) receives the new lincons.fixvars.chunks. */
+int32_t bh_proj_update_active_dev(bh_proj* P, const double* x_dev, const double* s_dev, const double* xlow_dev, const double* xupp_dev,
+                                  double delta, double atol, int32_t* n_at_bound, int32_t* n_fixed, int32_t* branch,
+                                  uint64_t* fix_chunks_out);
+/* norm_reduced_gradient(g, lincons) = norm(projection(lincons, -g)) — src/basic_tralcnlss.jl:869-875 (also criticality_measure :839). */
+int32_t bh_reduced_gradient_norm_dev(bh_proj* P, const double* g_dev, double* out);
+/* model_reduction = dot(g,s) + 0.5*vthv(H,s) — src/basic_tralcnlss.jl:458. */
+int32_t bh_model_reduction_dev(bh_hess* H, const double* g_dev, const double* s_dev, double* out);
 
 /* factor_to_boundary(p, w, w_l, w_u; atol) — src/basic_tralcnlss.jl:793-809, stand-alone (tests). */
 int32_t bh_factor_to_boundary(const double* p, const double* w, const double* w_l, const double* w_u,

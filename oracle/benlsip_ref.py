@@ -541,7 +541,10 @@ def solve_subproblem(x0, y, mu, residuals, nlconstraints, jac_res, jac_nlcons, c
     k = 1
     solved = False
     while (not solved) and k <= k_max:
-        s, pred = inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa3, ops, log)
+        if hasattr(ops, "inner_step"):       # backend owns the whole inner step (device-resident minor loop)
+            s, pred = ops.inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa3, log)
+        else:
+            s, pred = inner_step(x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa3, ops, log)
         x_next = x + s
         rx_next, cx_next = residuals(x_next), nlconstraints(x_next)
         mx_next = 0.5 * sqnorm(rx_next) + np.dot(y, cx_next) + 0.5 * mu * np.dot(cx_next, cx_next)   # :58

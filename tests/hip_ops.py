@@ -77,6 +77,31 @@ class HipOpsDeviceAll(HipOpsDeviceMinor):
         return s
 
 
+class HipOpsResident(HipOpsDeviceAll):
+    """Same, with the WHOLE inner step owned by the library's device-resident chain (bh.inner_step: bh_cauchy_step_dev,
+    bh_minor_iterate_dev, bh_step_accumulate_dev, bh_proj_update_active_dev, bh_reduced_gradient_norm_dev,
+    bh_model_reduction_dev — SURVEY.md §8 f-1/f-2): between the upload of x, g and the download of s no n-vector crosses PCIe."""
+
+    def __init__(self, bh):
+        super().__init__(bh)
+        self.loop_bytes = 0
+        self.loop_minor = 0
+
+    def inner_step(self, x, g, H, chol_aat_L, lincons, delta, nb_minor_step, kappa2, kappa3, log):
+        dev = self._dev(lincons)
+        s, pred, info = self.bh.inner_step(x, g, H, dev, delta, nb_minor_step, kappa2, kappa3, full_output=True)
+        lincons.fixvars = dev.fixvars.copy()
+        R.update_chol(lincons, chol_aat_L)          # the oracle-side object is brought to the state the reference leaves behind
+        self.n_pcg += len(info["minor"])
+        self.loop_bytes += info["pcie_bytes_in_loop"]
+        self.loop_minor += len(info["minor"]) + 1
+        self.last_info = info
+        if log is not None:
+            for st, iters, nfix, ratio in info["minor"]:
+                log.append(("minor", int(st), int(nfix), float(ratio)))
+        return s, pred
+
+
 class ShardedHipOps(HipOpsDeviceAll):
     """Row-sharded run: this rank's `residuals` / `jac_res` callbacks return rows [lo, hi) only, the
     library's communicator is up, and the three places where the driver touches residual rows directly — mx (:44,:58),

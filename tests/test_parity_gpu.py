@@ -423,10 +423,11 @@ def test_pcg_full_size_properties(bh):
 
 
 # ----------------------------------------------------------------------------- config 1 through the restated driver
-from hip_ops import HipOps, HipOpsDeviceAll, HipOpsDeviceMinor, ShadowOps  # noqa: E402  (backends of the restated driver)
+from hip_ops import HipOps, HipOpsDeviceAll, HipOpsDeviceMinor, HipOpsResident, ShadowOps  # noqa: E402  (backends of the restated driver)
 
 
-@pytest.mark.parametrize("ops_cls", [HipOps, HipOpsDeviceMinor, HipOpsDeviceAll], ids=["pcg_abi", "minor_iterate_abi", "cauchy_abi"])
+@pytest.mark.parametrize("ops_cls", [HipOps, HipOpsDeviceMinor, HipOpsDeviceAll, HipOpsResident],
+                         ids=["pcg_abi", "minor_iterate_abi", "cauchy_abi", "resident_inner_step"])
 def test_sphere_regression_through_c_abi(bh, capsys, ops_cls):
     """BASELINE config 1: test/problems/sphere_regression.jl with every hot-path call on the GPU; the three acceptance
     inequalities of :63-65 and agreement with the CPU oracle's solution."""
@@ -459,7 +460,7 @@ def test_sphere_regression_through_c_abi(bh, capsys, ops_cls):
         with capsys.disabled():
             print("    first driver decision that differs from the oracle's: log entry %d of %d: %s" % (diff[0], len(log_ref), diff[3]))
         assert_rounding_dominated(diff)
-    if ops_cls is HipOpsDeviceAll:
+    if ops_cls in (HipOpsDeviceAll, HipOpsResident):
         assert opt_measure < 4e-7
     else:
         assert opt_measure < 1e-7
@@ -891,16 +892,21 @@ def test_asynchronous_jacobian_ingest(bh, d, n, q, chunk_mb):
         bh.set_option("upload_chunk_mb", 64)
 
 
-def test_inner_step_device_chain_against_oracle(bh, capsys):
-    """One whole `inner_step` (src/basic_tralcnlss.jl:394-460: Cauchy search, then minor iterates) with every hot-path and
-    "next"-row call on the device (bh_cauchy_step, bh_minor_iterate, bh_hmul_add, bh_project, bh_vthv) against the
-    all-CPU oracle on a config-2-shaped instance; prints both wall times."""
+@pytest.mark.parametrize("d,n,mA", [(4096, 512, 0), (1500, 300, 4)])
+def test_inner_step_device_chain_against_oracle(bh, capsys, d, n, mA):
+    """One whole `inner_step` (src/basic_tralcnlss.jl:394-460: Cauchy search, then minor iterates) against the all-CPU
+    oracle, (a) with every hot-path and "next"-row call on the device but host vectors in between (bh_cauchy_step,
+    bh_minor_iterate, bh_hmul_add, bh_project, bh_vthv) and (b) DEVICE-RESIDENT: the library-side chain bh.inner_step, where
+    between the upload of x, g and the download of s no n-vector crosses PCIe (asserted on bh_stats' transfer counters) and the
+    active set grows on the device (bh_proj_update_active_dev: Gram downdate instead of a factor rebuild).  Same CG exit
+    status in every minor iterate, same final active set, same step; prints the wall times."""
     import time
-    d, n = 4096, 512
     J = R.synthetic_J(d, n, seed=1)
     inst = R.synthetic_box_vectors(d, n, fix_every=8)
-    A = np.zeros((0, n))
+    A = np.random.default_rng(5).standard_normal((mA, n))
     L0 = R.chol_lower(A @ A.T)
+    x = inst.x - A.T @ np.linalg.solve(A @ A.T, A @ inst.x) if mA else inst.x      # any x works: the step stays in null(A)
+    x = np.clip(x, inst.x_l, inst.x_u)
     g = J.T @ inst.r0
     delta = R.initial_tr(g)
 
@@ -909,18 +915,88 @@ def test_inner_step_device_chain_against_oracle(bh, capsys):
         H = ops.new_hessian(J, np.zeros((0, n)), 10.0)
         log = []
         t0 = time.perf_counter()
-        s, pred = R.inner_step(inst.x, g, H, L0, cons, delta, 50, 0.1, 0.1, ops=ops, log=log)
+        if hasattr(ops, "inner_step"):
+            s, pred = ops.inner_step(x, g, H, L0, cons, delta, 50, 0.1, 0.1, log)
+        else:
+            s, pred = R.inner_step(x, g, H, L0, cons, delta, 50, 0.1, 0.1, ops=ops, log=log)
         return s, pred, log, cons.fixvars.copy(), time.perf_counter() - t0
 
     s_ref, pred_ref, log_ref, fix_ref, t_cpu = run(R.NumpyOps())
     s, pred, log, fix, t_gpu = run(HipOpsDeviceAll(bh))
+    res = HipOpsResident(bh)
+    run(res)                                                         # warm-up (device vectors, kernels)
+    res = HipOpsResident(bh)
+    s_r, pred_r, log_r, fix_r, t_res = run(res)
+    per_iter = res.loop_bytes / max(res.loop_minor, 1)
     with capsys.disabled():
-        print("[inner_step d=%d n=%d] oracle (CPU) %.3f s, device chain %.3f s, %d minor iterates, %d active bounds"
-              % (d, n, t_cpu, t_gpu, len(log_ref), int(fix_ref.sum())))
-    assert [x[1] for x in log] == [x[1] for x in log_ref]          # same CG exit status in every minor iterate
-    assert np.array_equal(fix, fix_ref)                            # same final active set
-    assert relnorm(s, s_ref) <= 1e-6, relnorm(s, s_ref)
-    assert pred == pytest.approx(pred_ref, rel=1e-8)
+        print("[inner_step d=%d n=%d mA=%d] oracle (CPU) %.3f s, device ops with host vectors %.4f s, device-resident chain %.4f s; "
+              "%d minor iterates, %d active bounds; PCIe bytes inside the resident loop: %d (%.0f per minor iterate; one n-vector = %d)"
+              % (d, n, mA, t_cpu, t_gpu, t_res, len(log_ref), int(fix_ref.sum()), res.loop_bytes, per_iter, 8 * n))
+    for lg, sv, pv, fx in ((log, s, pred, fix), (log_r, s_r, pred_r, fix_r)):
+        assert [e[1] for e in lg] == [e[1] for e in log_ref]         # same CG exit status in every minor iterate
+        assert [e[2] for e in lg] == [e[2] for e in log_ref]         # same active-set size after every minor iterate
+        assert np.array_equal(fx, fix_ref)                           # same final active set
+        assert relnorm(sv, s_ref) <= 1e-6, relnorm(sv, s_ref)
+        assert pv == pytest.approx(pred_ref, rel=1e-8)
+    # no n-vector moved inside the loop: what crossed is the BitVector image (n/8 bytes) plus a few scalars per call
+    assert res.loop_bytes <= res.loop_minor * (n // 8 + 512)
+    assert per_iter < 8 * n / 4
+
+
+@pytest.mark.parametrize("n,mA,seed", [(40, 0, 1), (200, 5, 2), (700, 64, 3), (300, 100, 4)])
+def test_device_side_active_set_update_matches_oracle(bh, n, mA, seed):
+    """bh_proj_update_active_dev against the reference's active_bounds + add_active! / active_bounds!
+    (src/polyhedral_constraints.jl:203-261; src/basic_tralcnlss.jl:439-453): same |active_indx|, same branch, same fixvars, and
+    the projector of the updated set (factor obtained by a Gram DOWNDATE over the newly fixed columns) agrees with the
+    oracle's rebuilt-from-scratch one; then a second update on top of the first (incremental twice), and the :452 branch."""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    xl, xu = -np.ones(n), np.ones(n)
+    x = rng.uniform(-0.9, 0.9, n)
+    fix0 = np.zeros(n, dtype=bool)
+    fix0[rng.choice(n, n // 10, replace=False)] = True
+    x[fix0] = np.where(rng.random(int(fix0.sum())) < 0.5, -1.0, 1.0)
+    delta = 0.4
+    cons_o = R.make_mixed_constraints(A, L0, fix0, l=xl, u=xu)
+    cons = bh.MixedConstraints(A, None, fix0, l=xl, u=xu)
+    dv = {k: bh.DeviceVector(n, v) for k, v in (("x", x), ("xl", xl), ("xu", xu))}
+    ds = bh.DeviceVector(n)
+    lib = bh._lib.lib()
+    import ctypes as ct
+    chunks = np.zeros((n + 63) // 64, dtype=np.uint64)
+    s = np.zeros(n)
+    for rnd in range(3):
+        # a step that parks some free variables on their bound / on the trust-region face (round 2: enough of them for :452)
+        s = s.copy()
+        free = np.flatnonzero(~cons_o.fixvars)
+        if rnd < 2:
+            pick = rng.choice(free, min(max(1, len(free) // 8), len(free)), replace=False)
+            s[pick] = np.where(rng.random(len(pick)) < 0.5, np.maximum(xl[pick] - x[pick], -delta), np.minimum(xu[pick] - x[pick], delta))
+            rest = ~np.isin(np.arange(n), pick) & ~cons_o.fixvars
+            s[rest] = rng.uniform(-0.05, 0.05, int(rest.sum()))
+        else:
+            s[free] = -delta * np.sign(x[free])       # every free variable on the trust-region face, none on a true bound
+        ds.upload(s)
+        idx = R.active_bounds(cons_o, x, s, delta)                                   # :439
+        if mA + idx.shape[0] <= n:
+            R.add_active(cons_o, L0, idx)
+            branch_ref = 0
+        else:
+            R.active_bounds_inplace(cons_o, x + s, L0)
+            branch_ref = 1
+        n_at, n_fix, br = ct.c_int32(), ct.c_int32(), ct.c_int32()
+        cons._sync()
+        bh._lib.check(lib.bh_proj_update_active_dev(cons._h, dv["x"].ptr, ds.ptr, dv["xl"].ptr, dv["xu"].ptr, delta, R.SQRT_EPS,
+                                                    ct.byref(n_at), ct.byref(n_fix), ct.byref(br), bh._lib.ptr(chunks)), "update_active")
+        fix_dev = np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].astype(bool)
+        assert (n_at.value, br.value) == (idx.shape[0], branch_ref)
+        assert np.array_equal(fix_dev, cons_o.fixvars) and n_fix.value == int(cons_o.fixvars.sum())
+        cons._fixvars, cons._dirty = fix_dev, False
+        if mA + n_fix.value <= n and (mA == 0 or n_fix.value < n - mA):
+            r = rng.standard_normal(n)
+            v_ref = R.projection(cons_o, r)
+            assert np.linalg.norm(bh.projection(cons, r) - v_ref) <= 1e-10 * np.linalg.norm(r)
 
 
 def test_interleaved_handles_share_the_workspace_safely(bh):
