@@ -158,6 +158,95 @@ function BEnlsip.cauchy_step(x::Vector{Float64}, g::Vector{Float64}, H::BEnlsip.
     return s_c
 end
 
+# ---- optional: the whole inner step with its vectors resident in HBM (SURVEY.md §8 f-1 / f-2) -------------------------------
+# inner_step(x, g, H, chol_aat, lincons, delta, nb_minor_step, kappa2, kappa3) — src/basic_tralcnlss.jl:394-460.  The reference's
+# method moves s, w and g_minor through Julia arrays between every two calls; this method owns the loop and keeps them in HBM:
+# x, g go up once, s comes down once, and between them only scalars and the n/8-byte BitVector image of the active set cross
+# PCIe.  The active set grows on the device (bh_proj_update_active_dev: device-side active_bounds + a Gram downdate over the
+# newly fixed columns instead of the O(p^3) cholesky_aug_aat rebuild).  Opt-in, because it replaces a driver-level method:
+#     BEnlsipHIP.resident_inner_step!(true)
+# Executable mirror: benlsip.jl_amd/operators.py::inner_step (tests/test_parity_gpu.py::test_inner_step_device_chain_against_oracle).
+const RESIDENT_INNER_STEP = Ref(false)
+resident_inner_step!(flag::Bool = true) = (RESIDENT_INNER_STEP[] = flag)
+
+mutable struct DeviceVec
+    ptr::Ptr{Cvoid}
+end
+function DeviceVec(n::Integer)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:bh_dev_alloc, libbh), Int32, (Ref{Ptr{Cvoid}}, Int64), ref, 8 * max(n, 1)), "bh_dev_alloc")
+    dv = DeviceVec(ref[])
+    finalizer(x -> ccall((:bh_dev_free, libbh), Int32, (Ptr{Cvoid},), x.ptr), dv)
+    return dv
+end
+upload!(dv::DeviceVec, v::Vector{Float64}) = check(ccall((:bh_dev_upload, libbh), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), dv.ptr, v, 8 * length(v)), "bh_dev_upload")
+download!(v::Vector{Float64}, dv::DeviceVec) = check(ccall((:bh_dev_download, libbh), Int32, (Ptr{Float64}, Ptr{Cvoid}, Int64), v, dv.ptr, 8 * length(v)), "bh_dev_download")
+
+const RESIDENT = WeakKeyDict{BEnlsip.MixedConstraints{Float64},Dict{Symbol,DeviceVec}}()
+
+function BEnlsip.inner_step(x::Vector{Float64}, g::Vector{Float64}, H::BEnlsip.AlHessian{Float64},
+                            chol_aat::Cholesky{Float64,Matrix{Float64}}, lincons::BEnlsip.MixedConstraints{Float64},
+                            delta::Float64, nb_minor_step::Int, kappa2::Float64, kappa3::Float64)
+    if !RESIDENT_INNER_STEP[]
+        # the reference's own method (more general signature), whose calls still reach the device one by one
+        return invoke(BEnlsip.inner_step, Tuple{Vector{T},Vector{T},BEnlsip.AlHessian{T},Cholesky{T,Matrix{T}},
+                                                BEnlsip.MixedConstraints{T},T,Int,T,T} where T,
+                      x, g, H, chol_aat, lincons, delta, nb_minor_step, kappa2, kappa3)
+    end
+    (m, n) = size(lincons.lineq)
+    dv = get!(RESIDENT, lincons) do
+        d = Dict{Symbol,DeviceVec}(k => DeviceVec(n) for k in (:x, :g, :s, :w, :gm, :xlow, :xupp))
+        upload!(d[:xlow], lincons.xlow); upload!(d[:xupp], lincons.xupp)
+        d
+    end
+    upload!(dv[:x], x); upload!(dv[:g], g)
+    hH, hP = handle(H), handle(lincons)
+    chunks = lincons.fixvars.chunks                                   # written in place: lincons.fixvars follows the device
+    nbp = Ref{Int32}(0); nh = Ref{Int32}(0)
+    check(ccall((:bh_cauchy_step_dev, libbh), Int32,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{UInt64}, Ref{Int32}, Ref{Int32}),
+                hH, hP, dv[:x].ptr, dv[:g].ptr, dv[:xlow].ptr, dv[:xupp].ptr, delta, dv[:s].ptr, chunks, nbp, nh), "bh_cauchy_step_dev")   # :410
+    check(ccall((:bh_hmul_add_dev, libbh), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), hH, dv[:s].ptr, dv[:g].ptr, dv[:gm].ptr),
+          "bh_hmul_add_dev")                                                                                                          # :412
+    red_norm(v::DeviceVec) = (o = Ref{Float64}(0.0);
+                              check(ccall((:bh_reduced_gradient_norm_dev, libbh), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), hP, v.ptr, o),
+                                    "bh_reduced_gradient_norm_dev"); o[])
+    norm_reduced_g, norm_reduced_g_minor = red_norm(dv[:g]), red_norm(dv[:gm])                                                       # :420-421
+    approx_solved = norm_reduced_g_minor <= kappa3 * norm_reduced_g
+    max_minor_step = min(nb_minor_step, n - m - count(lincons.fixvars))                                                                # :425-426
+    j = 1; cg_stop = false
+    while j <= max_minor_step && !approx_solved && !cg_stop                                                                            # :430
+        status = Ref{Int32}(-1); iters = Ref{Int32}(0); nhm = Ref{Int32}(0); alpha = Ref{Float64}(0.0)
+        check(ccall((:bh_minor_iterate_dev, libbh), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Float64,
+                     Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Float64}),
+                    hH, hP, dv[:x].ptr, dv[:s].ptr, dv[:gm].ptr, dv[:xlow].ptr, dv[:xupp].ptr, delta, kappa2, sqrt(eps(Float64)), 1e-10,
+                    dv[:w].ptr, status, iters, nhm, alpha), "bh_minor_iterate_dev")                                                    # :434
+        cg_stop = status[] == 2                                       # negative_curvature
+        check(ccall((:bh_step_accumulate_dev, libbh), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                    hH, dv[:s].ptr, dv[:w].ptr, dv[:g].ptr, dv[:gm].ptr), "bh_step_accumulate_dev")                                  # :436-437
+        n_at = Ref{Int32}(0); n_fix = Ref{Int32}(0); branch = Ref{Int32}(0)
+        check(ccall((:bh_proj_update_active_dev, libbh), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ptr{UInt64}),
+                    hP, dv[:x].ptr, dv[:s].ptr, dv[:xlow].ptr, dv[:xupp].ptr, delta, sqrt(eps(Float64)), n_at, n_fix, branch, chunks),
+              "bh_proj_update_active_dev")                                                                                            # :439-453
+        if branch[] == 0
+            norm_reduced_g, norm_reduced_g_minor = red_norm(dv[:g]), red_norm(dv[:gm])                                               # :446-447
+            approx_solved = norm_reduced_g_minor <= kappa3 * norm_reduced_g
+        else
+            approx_solved = true
+        end
+        j += 1
+    end
+    mr = Ref{Float64}(0.0)
+    check(ccall((:bh_model_reduction_dev, libbh), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), hH, dv[:g].ptr, dv[:s].ptr, mr),
+          "bh_model_reduction_dev")                                                                                                   # :458
+    s = Vector{Float64}(undef, n)
+    download!(s, dv[:s])
+    BEnlsip.update_chol!(lincons, chol_aat)       # one refresh of the host factor (a no-op under skip_host_factor!)
+    return s, mr[]
+end
+
 # ---- optional: drop the host-side factor maintenance (SURVEY.md §8 f-1) ---------------------------------------------------
 # With the library's default reduced projection form the device factors A_free*A_free' (mA x mA) itself and never reads
 # lincons.chol.  The reference still rebuilds the augmented (mA+p) x (mA+p) factor from scratch in update_chol! after every
