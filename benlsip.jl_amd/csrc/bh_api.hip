@@ -33,6 +33,7 @@ struct CgWorkspace {
     double *w = nullptr, *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr, *g = nullptr, *wl = nullptr, *wu = nullptr;
     double *x = nullptr, *s = nullptr, *xlow = nullptr, *xupp = nullptr;   // minor_iterate staging
     double* hw = nullptr;          // H*w accumulated by the CG loop for minor_iterate's linesearch
+    double *p2 = nullptr, *gpart = nullptr, *rvpart = nullptr;   // two-kernel box iteration: p ping-pong, f2b terms per chunk, r.v partials (2 x n_pad/2)
     double* slab = nullptr;
     double* scalars = nullptr;     // 8 doubles (linesearch alpha, ...)
     CgState* d_state = nullptr;
@@ -101,6 +102,7 @@ struct Ctx {
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
+    int64_t opt_cg_fused = 1;        // box CG: two kernels per iteration (H*p with the p-update folded in + reduce/update) instead of three
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
     int64_t opt_upload_chunk_mb = 64; // bh_hess_create_async: MiB of J per pipelined column chunk
     int64_t opt_ev_stride = 8;       // BH_FLAG_PROFILE: hipEvents around every opt_ev_stride-th H*p launch of a handle
@@ -238,6 +240,12 @@ void launch_rs_mode(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
     }
 }
 
+// MODE_FUSED with the CG prologue (two-kernel box iteration); default geometries only.
+template <int T, int CPT, int R>
+void launch_rs_cgp(const RowStreamArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 0, 1>), dim3(grid), dim3(T), 0, s, a);
+}
+
 // n <= 16384: J v and J'u keep everything in registers; the fused mode needs the v slice in LDS (T * CPT * 16 bytes = 128 KiB,
 // above the 64 KiB a kernel may use without asking).
 template <int T, int CPT, int R>
@@ -269,6 +277,29 @@ void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipS
         case 13: launch_rs_mode<256, 8, 6, 1, 0>(mode, a, grid, s); break;
         case 14: launch_rs_mode_vlds<512, 16, 1>(mode, a, grid, s); break;
         default: launch_rs_mode<512, 4, 2>(mode, a, grid, s); break;
+    }
+}
+
+bool cgp_supported(int cfg) { return cfg <= 5 || cfg == 14; }
+void launch_row_stream_cgp(int cfg, const RowStreamArgs& a, int grid, hipStream_t s) {
+    switch (cfg) {
+        case 0: launch_rs_cgp<64, 1, 8>(a, grid, s); break;
+        case 1: launch_rs_cgp<256, 1, 8>(a, grid, s); break;
+        case 2: launch_rs_cgp<256, 2, 8>(a, grid, s); break;
+        case 3: launch_rs_cgp<256, 4, 4>(a, grid, s); break;
+        case 4: launch_rs_cgp<256, 8, 4>(a, grid, s); break;
+        case 5: launch_rs_cgp<512, 8, 2>(a, grid, s); break;
+        default: {
+            constexpr size_t lds = (size_t)512 * 16 * sizeof(double2);
+            static bool attr_set = false;      // (per process; bh_shutdown + bh_init keep the same code object)
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>), dim3(grid), dim3(512), lds, s, a);
+            break;
+        }
     }
 }
 
@@ -343,17 +374,19 @@ namespace {
 int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
     CgWorkspace& c = g_ctx.cg;
     if (c.n_pad < n_pad) {
-        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.g, &c.wl, &c.wu, &c.x, &c.s, &c.xlow, &c.xupp, &c.hw};
+        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.g, &c.wl, &c.wu, &c.x, &c.s, &c.xlow, &c.xupp, &c.hw, &c.p2, &c.gpart, &c.rvpart};
+        constexpr int NV = 16;
         dev_free(c.slab);
         c.slab = nullptr;
-        BH_TRY(dev_alloc(&c.slab, 13 * n_pad + 8));
-        BH_HIP(hipMemsetAsync(c.slab, 0, (size_t)(13 * n_pad + 8) * sizeof(double), g_ctx.stream));
-        for (int i = 0; i < 13; ++i) *vecs[i] = c.slab + (int64_t)i * n_pad;
-        c.scalars = c.slab + 13 * n_pad;
+        BH_TRY(dev_alloc(&c.slab, NV * n_pad + 8));
+        BH_HIP(hipMemsetAsync(c.slab, 0, (size_t)(NV * n_pad + 8) * sizeof(double), g_ctx.stream));
+        for (int i = 0; i < NV; ++i) *vecs[i] = c.slab + (int64_t)i * n_pad;
+        c.scalars = c.slab + NV * n_pad;
         c.n_pad = n_pad;
     }
     if (!c.d_state) {
         BH_TRY(dev_alloc(&c.d_state, 1));
+        BH_HIP(hipMemsetAsync(c.d_state, 0, sizeof(CgState), g_ctx.stream));
         void* hp = nullptr;
         BH_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));
         memset(hp, 0, 64);
@@ -376,18 +409,21 @@ int32_t check_peer_error();
 int32_t hess_ready(bh_hess* H);
 
 // Spin on the host-mapped progress word until this call's tag shows `done` or at least `target` H*p products.
-int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
+// iter_target > 0: also return once the reference's `iter` has reached it (two-kernel box iteration: the H*p launch of
+// iteration j publishes iter = j when its prologue has decided that the loop goes on).
+int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out, int iter_target = 0) {
     const auto t0 = std::chrono::steady_clock::now();
     unsigned long long spins = 0;
+    auto reached = [&](unsigned long long w, MirrorWord* m) {
+        if (((w >> 48) & 0xffffu) != (tag & 0xffffu)) return false;
+        m->status = (int)((w >> 44) & 0xf);
+        m->done = (int)((w >> 40) & 0xf);
+        m->iter = (int)((w >> 20) & 0xfffff);
+        m->n_hmul = (int)(w & 0xfffff);
+        return m->done != 0 || m->n_hmul >= target || (iter_target > 0 && m->iter >= iter_target);
+    };
     while (true) {
-        const unsigned long long w = *c.h_mirror;
-        if (((w >> 48) & 0xffffu) == (tag & 0xffffu)) {
-            out->status = (int)((w >> 44) & 0xf);
-            out->done = (int)((w >> 40) & 0xf);
-            out->iter = (int)((w >> 20) & 0xfffff);
-            out->n_hmul = (int)(w & 0xfffff);
-            if (out->done || out->n_hmul >= target) return BH_OK;
-        }
+        if (reached(*c.h_mirror, out)) return BH_OK;
         __builtin_ia32_pause();
         if ((++spins & 0xffff) == 0) {
             if (g_ctx.peer.active && *g_ctx.peer.h_err != 0ull) return check_peer_error();
@@ -395,9 +431,8 @@ int32_t wait_mirror(CgWorkspace& c, unsigned tag, int target, MirrorWord* out) {
             if (q != hipSuccess && q != hipErrorNotReady) return fail(BH_ERR_HIP, std::string("CG loop: ") + hipGetErrorString(q));
             if (q == hipSuccess) {
                 // everything enqueued has run: the word is final.  Not reaching the target now is a logic error, not a wait.
-                const unsigned long long w2 = *c.h_mirror;
-                const bool ok = ((w2 >> 48) & 0xffffu) == (tag & 0xffffu) && ((((w2 >> 40) & 0xf) != 0) || (int)(w2 & 0xfffff) >= target);
-                if (!ok) return fail(BH_ERR_HIP, "internal: stream drained but the loop state did not reach the launch target");
+                MirrorWord m2{};
+                if (!reached(*c.h_mirror, &m2)) return fail(BH_ERR_HIP, "internal: stream drained but the loop state did not reach the launch target");
                 continue;
             }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
@@ -496,6 +531,21 @@ int32_t launch_jtv_panels(bh_hess* H, const double* u, double* z_out, int64_t nr
     return reduce_slabs(H, grid, z_out, state);       // includes the all-reduce over ranks
 }
 
+// BH_FLAG_PROFILE: records the start event of an H*p launch when this launch is sampled; *slot >= 0 then names the pair.
+int32_t profile_begin(bh_hess* H, int ev_index, int* slot) {
+    *slot = -1;
+    if (!(g_ctx.flags & BH_FLAG_PROFILE) || ev_index < 0) return BH_OK;
+    if ((H->hmul_seq++ % (uint64_t)g_ctx.opt_ev_stride) != 0 || (int)H->ev_pending.size() >= kEvCap) return BH_OK;
+    if (H->ev.empty()) {
+        H->ev.resize(2 * kEvCap, nullptr);
+        for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
+    }
+    *slot = (int)H->ev_pending.size();
+    H->ev_pending.push_back(ev_index);
+    BH_HIP(hipEventRecord(H->ev[2 * *slot], g_ctx.stream));
+    return BH_OK;
+}
+
 // z_out (ld doubles, device) = sum over ranks of J_k'(W .* (J_k v)), v = v_pad (ld doubles, zero padded).
 int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgState* state, int ev_index, int reverse = 0,
                     bool negate = false, const int* negmask = nullptr) {
@@ -513,22 +563,10 @@ int32_t launch_hmul(bh_hess* H, const double* v_pad, double* z_out, const CgStat
     a.negate = negate ? 1 : 0; a.negmask = negmask;
     // BH_FLAG_PROFILE: hipEvents around every opt_ev_stride-th (default 8th) H*p launch of this handle, counted ACROSS calls
     // (an event pair costs ~10 us of stream time; timing every launch would slow the loop it measures by 3 %).
-    bool timed = false;
     int slot = -1;
-    if ((g_ctx.flags & BH_FLAG_PROFILE) && ev_index >= 0) {
-        if ((H->hmul_seq++ % (uint64_t)g_ctx.opt_ev_stride) == 0 && (int)H->ev_pending.size() < kEvCap) {
-            if (H->ev.empty()) {
-                H->ev.resize(2 * kEvCap, nullptr);
-                for (auto& e : H->ev) BH_HIP(hipEventCreate(&e));
-            }
-            slot = (int)H->ev_pending.size();
-            H->ev_pending.push_back(ev_index);
-            timed = true;
-            BH_HIP(hipEventRecord(H->ev[2 * slot], g_ctx.stream));
-        }
-    }
+    BH_TRY(profile_begin(H, ev_index, &slot));
     launch_row_stream(cfg, MODE_FUSED, a, grid, g_ctx.stream);
-    if (timed) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], g_ctx.stream));
+    if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], g_ctx.stream));
     return reduce_slabs(H, grid, z_out, state);
 }
 
@@ -981,6 +1019,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(0, atoll(s));
     if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_PROJ_FORM")) g_ctx.opt_proj_form = atoll(s) ? 1 : 0;
+    if (const char* s = getenv("BH_CG_FUSED")) g_ctx.opt_cg_fused = atoll(s) ? 1 : 0;
     g_ctx.init = true;
     return BH_OK;
 }
@@ -1043,6 +1082,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cg_fused")) { g_ctx.opt_cg_fused = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
@@ -1702,6 +1742,80 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     a.hw = hw;
 
     const bool box = (P->mA == 0);
+    // Box constraints, one rank, J rows register-resident: TWO kernels per iteration instead of three (bh_cgfuse.hip.h) — the
+    // H*p launch forms p on the fly and takes the exit test, one 128-workgroup kernel reduces the slabs and updates w, r, v.
+    // (g doubles as the first H*p input, so it must be readable up to the padded length: workspace copy or n == ld.)
+    const int rs_cfg = multi_panel(H) ? -1 : pick_config(H->nchunks);
+    if (box && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && !comm_active() && max_iter >= 1 && (gp == c.g || n == n_pad)) {
+        BH_TRY(hess_ready(H));
+        if (gp == c.g && n < n_pad) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
+        const int64_t nrows = H->d + H->q_eff;
+        const int grid = grid_for(rs_cfg, nrows);
+        const int nblk = (H->nchunks + 15) / 16;
+        double* pbuf[2] = {c.p, c.p2};
+        double* rvbuf[2] = {c.rvpart, c.rvpart + n_pad / 2};
+        auto launch_stream = [&](int j) -> int32_t {            // H*p of iteration j (1-based), p_j formed on the fly
+            RowStreamArgs ra = rs_args(H, nrows, nullptr);
+            ra.partials = H->partials;
+            ra.v = gp; ra.negate = 1; ra.negmask = a.fixrank;                       // used by j == 1 only: p_1 = -mask(g)
+            CgFuse& f = ra.cf;
+            f.st = c.d_state; f.j = j; f.n = (int)n; f.max_iter = max_iter;
+            f.vvec = c.v; f.p_old = pbuf[(j - 1) & 1]; f.p_new = pbuf[j & 1];
+            f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nblk;
+            f.w = wp; f.wl = wlp; f.wu = wup;
+            f.sqpart = H->sq_partials; f.gpart = c.gpart;
+            f.kappa2 = kappa2; f.atol_f2b = atol_f2b;
+            f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
+            int slot = -1;
+            BH_TRY(profile_begin(H, j - 1, &slot));
+            launch_row_stream_cgp(rs_cfg, ra, grid, s);
+            if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], s));
+            return BH_OK;
+        };
+        auto launch_update = [&](int j) {
+            CgUpdArgs u{};
+            u.st = c.d_state; u.j = j; u.partials = H->partials; u.ld = H->ld; u.nchunks = H->nchunks; u.G = grid;
+            u.sqpart = H->sq_partials; u.gpart = c.gpart; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nblk;
+            u.p = pbuf[j & 1]; u.w = wp; u.hw = hw; u.r = c.r; u.g = gp; u.v = c.v; u.fixrank = a.fixrank;
+            u.n = (int)n; u.atol_neg = atol_negcurv; u.trace = a.trace; u.trace_cap = a.trace_cap; u.mirror = a.mirror; u.tag = a.tag;
+            hipLaunchKernelGGL(cg_reduce_update_kernel, dim3(nblk), dim3(256), 0, s, u);
+        };
+        // Launch order: S(1) | U(1) S(2) | U(2) S(3) | ...: the stream kernel of iteration j+1 is what detects "solved" after
+        // iteration j, so it is always enqueued together with U(j) (as a gated no-op if the loop ended in U(j)).
+        BH_TRY(launch_stream(1));
+        int launched = 0;                                          // iterations whose U has been enqueued
+        auto launch_batch = [&](int nb) -> int32_t {
+            nb = std::min(nb, max_iter - launched);
+            for (int i = 0; i < nb; ++i) {
+                launch_update(launched + 1);
+                BH_TRY(launch_stream(launched + 2));               // (iteration max_iter + 1 only ever runs its prologue: iter > max_iter)
+                launched += 1;
+            }
+            BH_HIP(hipGetLastError());
+            return BH_OK;
+        };
+        const int batch = launch_batch_size(H);
+        MirrorWord mw{};
+        const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : std::min(batch, 2);
+        constexpr int kNever = 0x7fffffff;
+        BH_TRY(launch_batch(first));
+        // S(launched + 1) speaks for iteration `launched`: either "stopped" (done) or "iter = launched + 1, streaming"
+        BH_TRY(wait_mirror(c, a.tag, kNever, &mw, launched + 1));
+        if (!mw.done && launched < max_iter) {
+            BH_TRY(launch_batch(batch));
+            while (true) {
+                const int target = launched;             // everything enqueued so far except the batch launched next
+                const bool more = launched < max_iter;
+                if (more) BH_TRY(launch_batch(batch));
+                BH_TRY(wait_mirror(c, a.tag, kNever, &mw, target + 1));
+                if (mw.done || !more) break;
+            }
+        }
+        BH_TRY(wait_mirror(c, a.tag, kNever, &mw));          // the final state
+        if (!mw.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
+        fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
+        return BH_OK;
+    }
     // Box constraints with register-resident vectors: no init kernel — the first H*p forms p0 = -mask(g) on the fly and
     // the first step kernel does the initialisation of :702-718 itself.
     // (g doubles as the H*p input there, so it must be readable up to the padded length: workspace copy or n == ld.)

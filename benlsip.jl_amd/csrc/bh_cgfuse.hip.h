@@ -1,0 +1,171 @@
+// bh_cgfuse.hip.h — second kernel of the two-kernel box-constrained CG iteration
+// Part of the single translation unit of bh_api.hip (see bh_kernels.hip.h for the layout and design notes).
+//
+// One iteration of projected_cg (src/basic_tralcnlss.jl:722-750) used to be three launches: H*p stream, slab reduction,
+// single-workgroup step kernel.  For box constraints (projection = mask) it is two:
+//   row_stream_kernel<..., CGP = 1>(j)   forms p_j = -v + beta p_{j-1} on the fly (beta and the exit test |r.v| < tol_cg come
+//                                         from the partial sums the update kernel of iteration j-1 left), streams J once,
+//                                         leaves the per-workgroup slabs of J'(W.(J p)), the partial sums of p'Hp = sum_i
+//                                         w_i (Jp)_i^2 and the factor_to_boundary terms of p_j;
+//   cg_reduce_update_kernel(j)            128 workgroups: each recomputes the iteration's scalars (pHp, gamma, r.v, alpha and the
+//                                         branch of :725-739 — identical bits everywhere: shape-independent wave reductions),
+//                                         sums ITS 32 columns of the slabs and updates ITS 32 entries of w, H*w, r, v at once,
+//                                         leaving its partial of the next r.v.
+// No workgroup ever reads a word its own launch writes: scalars that change are either recomputed from partials or read
+// from CgState fields that only the PREVIOUS launch wrote; the exit is signalled through CgState::stop_at (iteration
+// number), which gates launches of later iterations only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bh_reduce.hip.h"
+#include "bh_cg.hip.h"
+
+namespace bh {
+
+struct CgUpdArgs {
+    CgState* st;
+    int j;                          // iteration (1-based) = number of the H*p product being consumed
+    const double* partials; int64_t ld; int nchunks; int G;      // slabs of the preceding row_stream launch
+    const double* sqpart;           // [G]
+    const double* gpart;            // [nchunks]
+    const double* rvpart_in;        // [nrv] partials of r.v from iteration j-1   (j >= 2)
+    double* rvpart_out;             // [gridDim.x]
+    int nrv;
+    const double* p;                // p_j
+    double* w; double* hw;          // hw may be NULL
+    double* r; const double* g;     // j == 1: r = g_minor (:705), w = 0 (:702)
+    double* v;
+    const int* fixrank;             // NULL: nothing fixed
+    int n;
+    double atol_neg;
+    double* trace; int trace_cap;
+    unsigned long long* mirror; unsigned tag;
+};
+
+// grid = ceil(nchunks / 16) workgroups of 256 threads = 16 chunks x 16 slab lanes (as reduce_partials_kernel).
+__global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
+    CgState* st = a.st;
+    if (st->stop_at != 0 && a.j > st->stop_at) return;
+    __shared__ double2 sm[16][17];
+    __shared__ double rvs[16];
+    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool valid = c < a.nchunks;
+    const int64_t ld2 = a.ld >> 1;
+    const double QNAN = __longlong_as_double(0x7ff8000000000000ll);
+
+    // ---- this workgroup's 32 columns of Hp = sum of the slabs (fixed order) --------------------------------------------
+    const double2* P2 = reinterpret_cast<const double2*>(a.partials);
+    double2 acc = make_double2(0.0, 0.0);
+    if (valid) {
+        int g = rl;
+        for (; g + 48 < a.G; g += 64) {
+            const double2 x0 = P2[(int64_t)g * ld2 + c];
+            const double2 x1 = P2[(int64_t)(g + 16) * ld2 + c];
+            const double2 x2 = P2[(int64_t)(g + 32) * ld2 + c];
+            const double2 x3 = P2[(int64_t)(g + 48) * ld2 + c];
+            acc.x += x0.x; acc.y += x0.y;
+            acc.x += x1.x; acc.y += x1.y;
+            acc.x += x2.x; acc.y += x2.y;
+            acc.x += x3.x; acc.y += x3.y;
+        }
+        for (; g < a.G; g += 16) {
+            const double2 x0 = P2[(int64_t)g * ld2 + c];
+            acc.x += x0.x; acc.y += x0.y;
+        }
+    }
+    sm[rl][cl] = acc;
+
+    // ---- the iteration's scalars, recomputed by every wave from the partials (identical bits everywhere) -----------------
+    const double pHp = wave_fixed_sum(a.sqpart, a.G);                                  // :723
+    const double gamma = wave_fixed_min(a.gpart, a.nchunks);                           // :728 / :734
+    const double rtv = (a.j == 1) ? st->rtv : wave_fixed_sum(a.rvpart_in, a.nrv);      // :732  (j == 1: written by the H*p launch)
+    int cont = 0, neg = 0, outside = 0;
+    double step = 0.0, alpha = QNAN;
+    bool add_w = true;
+    if (pHp <= a.atol_neg) {                        // :725
+        neg = 1;
+        if (fabs(pHp) > a.atol_neg) step = gamma;   // :727-729
+        else add_w = false;
+    } else {
+        alpha = __ddiv_rn(rtv, pHp);                // :733
+        outside = alpha > gamma;                    // :735
+        if (outside) step = gamma;                  // :737
+        else { step = alpha; cont = 1; }            // :739
+    }
+    __syncthreads();
+
+    // ---- update this workgroup's entries ----------------------------------------------------------------------------------
+    double rv_part = 0.0;
+    if (rl == 0 && valid) {
+        double2 hp = sm[0][cl];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { hp.x += sm[q][cl].x; hp.y += sm[q][cl].y; }
+        const bool full = (2 * c + 1) < a.n;
+        const double2 pk = reinterpret_cast<const double2*>(a.p)[c];
+        double2 wk = make_double2(0.0, 0.0), hwk = make_double2(0.0, 0.0), rk;
+        if (a.j == 1) {
+            rk = reinterpret_cast<const double2*>(a.g)[c];
+            if (!full) rk.y = 0.0;                                   // odd n: never trust the element past the end
+        } else {
+            rk = reinterpret_cast<const double2*>(a.r)[c];
+            if (full) wk = reinterpret_cast<const double2*>(a.w)[c]; else wk.x = a.w[2 * c];
+            if (a.hw != nullptr) { if (full) hwk = reinterpret_cast<const double2*>(a.hw)[c]; else hwk.x = a.hw[2 * c]; }
+        }
+        int2 fr = make_int2(-1, -1);
+        if (a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[c];
+        if (add_w) {
+            wk.x = __dadd_rn(wk.x, __dmul_rn(step, pk.x));           // :729 / :737 / :739
+            hwk.x = __dadd_rn(hwk.x, __dmul_rn(step, hp.x));
+            if (full) {
+                wk.y = __dadd_rn(wk.y, __dmul_rn(step, pk.y));
+                hwk.y = __dadd_rn(hwk.y, __dmul_rn(step, hp.y));
+            }
+        }
+        double2 vk = make_double2(0.0, 0.0);
+        if (cont) {
+            rk.x = __dadd_rn(rk.x, __dmul_rn(alpha, hp.x));          // :740
+            rk.y = __dadd_rn(rk.y, __dmul_rn(alpha, hp.y));
+            vk.x = (fr.x >= 0) ? 0.0 : rk.x;                         // projection!, box case (:741)
+            vk.y = (fr.y >= 0) ? 0.0 : rk.y;
+            rv_part = fma(rk.y, vk.y, rk.x * vk.x);                  // :743 (this chunk)
+        }
+        // stores: never beyond n (w += Inf*0 would poison the padding)
+        if (add_w || a.j == 1) {
+            if (full) reinterpret_cast<double2*>(a.w)[c] = wk; else a.w[2 * c] = wk.x;
+            if (a.hw != nullptr) { if (full) reinterpret_cast<double2*>(a.hw)[c] = hwk; else a.hw[2 * c] = hwk.x; }
+        }
+        if (cont || a.j == 1) {
+            if (full) { reinterpret_cast<double2*>(a.r)[c] = rk; reinterpret_cast<double2*>(a.v)[c] = vk; }
+            else { a.r[2 * c] = rk.x; a.v[2 * c] = vk.x; }
+        }
+    }
+    if (rl == 0) rvs[cl] = rv_part;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += rvs[q];
+        a.rvpart_out[blockIdx.x] = t;
+    }
+
+    // ---- workgroup 0 commits the iteration ----------------------------------------------------------------------------------
+    if (blockIdx.x == 0 && tid == 0) {
+        st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = a.j; st->rtv = rtv;
+        st->neg_curvature = neg; st->outside_region = outside; st->need_proj = 0; st->iter = a.j;
+        tie_note_step_a(st, pHp, a.atol_neg, alpha, gamma, a.j);
+        if (a.trace != nullptr && a.j <= a.trace_cap) {
+            double* row = a.trace + 4 * (int64_t)(a.j - 1);
+            row[0] = pHp; row[1] = alpha; row[2] = (neg && !add_w) ? QNAN : gamma; row[3] = rtv;   // [3]: r.v after :746 follows in the next launch
+        }
+        if (!cont) {
+            st->approx_solved = 0; st->done = 1; st->stop_at = a.j;
+            st->status = cg_final_status(st);
+        }
+        CgArgs pa{};
+        pa.mirror = a.mirror; pa.tag = a.tag;
+        publish_state(pa, st);                  // progress (n_hmul = j) or the final state
+    }
+}
+
+}  // namespace bh

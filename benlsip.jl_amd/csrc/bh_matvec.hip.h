@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "bh_reduce.hip.h"
+#include "bh_cg.hip.h"
 
 namespace bh {
 
@@ -15,6 +16,26 @@ namespace bh {
 //   reduction so they stay in flight across the barrier.
 // ------------------------------------------------------------------------------------------
 enum { MODE_JV = 0, MODE_JTV = 1, MODE_FUSED = 2 };
+
+// Two-kernel box-constrained CG iteration ("Device-resident CG"): the H*p launch of iteration j forms p_j itself
+// (CGP = 1) from what cg_reduce_update_kernel(j-1) left behind, and decides the loop's exit test on the way in.
+struct CgFuse {
+    CgState* st;
+    int j;                  // iteration of this launch, 1-based (the reference's `iter` while the H*p of :722 runs)
+    int n, max_iter;
+    const double* vvec;     // v = P(r) after iteration j-1                (j >= 2)
+    const double* p_old;    // p_{j-1}                                     (j >= 2)
+    double* p_new;          // p_j: every workgroup stores the chunks it owns (chunk c belongs to workgroup c % gridDim.x)
+    const double* rvpart;   // partial sums of r.v written by cg_reduce_update_kernel(j-1)
+    int nrv;
+    const double* w;        // w after iteration j-1 (j == 1: w = 0)
+    const double* wl; const double* wu;
+    double* sqpart;         // [gridDim.x]  sum over this workgroup's rows of weight_i * (J p)_i^2   ->  pHp
+    double* gpart;          // [nchunks]    factor_to_boundary terms of p_j, per chunk               ->  gamma
+    double kappa2, atol_f2b;
+    double* trace; int trace_cap;
+    unsigned long long* mirror; unsigned tag;
+};
 
 struct RowStreamArgs {
     const double* J;        // row-major image, (nrows) x ld
@@ -34,6 +55,7 @@ struct RowStreamArgs {
     int weighted_u;         // JTV: coefficient u[row] * (row < d_rows ? 1 : mu)  (second pass of the two-pass H*p)
     int negate;             // JV/FUSED: use -mask(v) instead of v (first CG iteration: p0 = -P(g) for box constraints, :706-708)
     const int* negmask;     // fixrank (>= 0: fixed -> 0) or NULL, with negate
+    CgFuse cf;              // CGP = 1 only
 };
 
 // NT: J is read exactly once per launch -> non-temporal loads (global_load_dwordx4 ... nt): measured +10 % (6.39 -> 7.05 TB/s).
@@ -42,43 +64,31 @@ struct RowStreamArgs {
 // VL: 1 = each lane parks its slice of v in LDS (dynamic, nchunks x 16 bytes, lane-private slots: no barrier, no bank
 // conflicts) instead of registers.  For 8192 < n <= 16384 the two row buffers and the z accumulators of the fused mode
 // fill the register file on their own; the 128 KiB of LDS a CU has left over hold v.
-template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1, int VL = 0>
+// CGP: 1 = MODE_FUSED launch of the two-kernel box CG iteration: the prologue below forms p_j (and the loop's exit test)
+// while the first row group is already on its way from HBM.
+template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1, int VL = 0, int CGP = 0>
 __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
-    if (a.state != nullptr && a.state->done) return;
+    if (!CGP && a.state != nullptr && a.state->done) return;
+    if (CGP && a.cf.j > 1 && a.cf.st->stop_at != 0 && a.cf.j > a.cf.st->stop_at) return;   // the loop stopped before this iteration
     constexpr int NW = T / 64;
     __shared__ double red[2][R][NW];
+    __shared__ double pro[2][NW];                                       // CGP, iteration 1, workgroup 0 only
     extern __shared__ __attribute__((aligned(16))) double2 v_lds[];     // VL only: [CPT][T]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t ld2 = a.ld >> 1;   // row stride in double2
     const double2* __restrict__ J2 = reinterpret_cast<const double2*>(a.J);
+    const int64_t ngroups = (a.nrows + R - 1) / R;
+    const int64_t G = gridDim.x;
 
     bool act[CPT];
     double2 vv[CPT], zz[CPT];
 #pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int c = tid + k * T;
-        act[k] = c < a.nchunks;
-        vv[k] = make_double2(0.0, 0.0);
-        zz[k] = make_double2(0.0, 0.0);
-        if (MODE != MODE_JTV && act[k]) {
-            vv[k] = reinterpret_cast<const double2*>(a.v)[c];
-            if (a.negate) {
-                int2 f = make_int2(-1, -1);
-                if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
-                vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
-                vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
-            }
-        }
-        if (VL && MODE != MODE_JTV) v_lds[k * T + tid] = vv[k];      // read back only by this lane
-    }
-
-    const int64_t ngroups = (a.nrows + R - 1) / R;
-    const int64_t G = gridDim.x;
-    double sq_acc = 0.0;
-    int buf = 0;
+    for (int k = 0; k < CPT; ++k) act[k] = (tid + k * T) < a.nchunks;
 
     double2 A[R][CPT], B[R][CPT];
+    double sq_acc = 0.0;
+    int buf = 0;
 
     auto load_group = [&](double2 (&dst)[R][CPT], int64_t grp) {
         if (a.reverse) grp = ngroups - 1 - grp;
@@ -154,7 +164,10 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
             } else {
                 double coef;
                 if (MODE == MODE_JTV) coef = rv ? (a.weighted_u && row >= a.d_rows ? a.mu * a.u[row] : a.u[row]) : 0.0;
-                else coef = (row < a.d_rows) ? s[r] : a.mu * s[r];
+                else {
+                    coef = (row < a.d_rows) ? s[r] : a.mu * s[r];
+                    if (CGP && rv) sq_acc = fma(coef, s[r], sq_acc);          // p'Hp = sum_i weight_i (J p)_i^2
+                }
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
                     zz[k].x = fma(coef, X[r][k].x, zz[k].x);
@@ -165,13 +178,108 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     };
 
     int64_t g = blockIdx.x;
+    // the first row group does not depend on the vector: its loads go out before the vector (or the CG prologue) is touched
+    if (PF && g < ngroups) load_group(A, g);
+
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int c = tid + k * T;
+        vv[k] = make_double2(0.0, 0.0);
+        zz[k] = make_double2(0.0, 0.0);
+        if (MODE != MODE_JTV && act[k] && !(CGP && a.cf.j > 1)) {
+            vv[k] = reinterpret_cast<const double2*>(a.v)[c];
+            if (a.negate) {
+                int2 f = make_int2(-1, -1);
+                if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
+                vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
+                vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
+            }
+        }
+    }
+    if (CGP) {
+        const CgFuse& f = a.cf;
+        CgState* st = f.st;
+        if (f.j == 1) {
+            // projected_cg's initialisation (:702-718) belongs to workgroup 0: r = g, v = P(r) = mask(g), p = -v (formed above),
+            // rtv = r.v, tol_cg = kappa2*||v||, iter = 1, all flags down
+            if (blockIdx.x == 0) {
+                double rtv0 = 0.0, vv0 = 0.0;
+#pragma unroll
+                for (int k = 0; k < CPT; ++k) {        // vv = -mask(g):  r.v = v.v = sum of squares of the free components
+                    rtv0 = fma(vv[k].x, vv[k].x, rtv0); rtv0 = fma(vv[k].y, vv[k].y, rtv0);
+                }
+                rtv0 = wave_sum(rtv0);
+                if (lane == 0) pro[0][wave] = rtv0;
+                __syncthreads();
+                if (tid == 0) {
+                    double t = 0.0;
+                    for (int w2 = 0; w2 < NW; ++w2) t += pro[0][w2];
+                    vv0 = t;
+                    st->rtv = t;                                   // :707  (r.v with v = mask(r))
+                    st->tol_cg = f.kappa2 * sqrt(vv0);             // :710
+                    st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
+                    st->iter = 1; st->max_iter = f.max_iter;
+                    st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
+                    st->n_hmul = 0; st->need_proj = 0; st->done = 0; st->status = 4; st->stop_at = 0;
+                    tie_reset(st);
+                }
+            }
+        } else {
+            const double rtv_next = wave_fixed_sum(f.rvpart, f.nrv);          // :743, same bits in every wave of every workgroup
+            const double rtv = st->rtv, tol_cg = st->tol_cg;
+            const bool solved = fabs(rtv_next) < tol_cg;                       // :747
+            const bool stop = solved || f.j > f.max_iter;                      // :720 with iter = j after :748
+            const double beta = __ddiv_rn(rtv_next, rtv);                      // :744
+            if (blockIdx.x == 0 && tid == 0) {
+                tie_note(st, TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), f.j - 1);
+                if (f.trace != nullptr && f.j - 1 <= f.trace_cap) f.trace[4 * (int64_t)(f.j - 2) + 3] = rtv_next;
+                st->iter = f.j;                        // :748 (nobody reads it back: the kernels count iterations by launch)
+                if (stop) {
+                    st->beta = beta; st->rtv = rtv_next; st->approx_solved = solved ? 1 : 0;
+                    st->done = 1; st->stop_at = f.j - 1;
+                    st->status = cg_final_status(st);
+                }
+                CgArgs pa{};
+                pa.mirror = f.mirror; pa.tag = f.tag;
+                publish_state(pa, st);                 // "stopped after iteration j-1", or "iter = j: iteration j is streaming"
+            }
+            if (stop) return;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                if (!act[k]) continue;
+                const int c = tid + k * T;
+                const double2 vk = reinterpret_cast<const double2*>(f.vvec)[c];
+                const double2 po = reinterpret_cast<const double2*>(f.p_old)[c];
+                vv[k].x = __dadd_rn(-vk.x, __dmul_rn(beta, po.x));             // :745
+                vv[k].y = __dadd_rn(-vk.y, __dmul_rn(beta, po.y));
+            }
+        }
+        // the chunks this workgroup owns: store p_j, and their factor_to_boundary terms (:734 / :728)
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + k * T;
+            if (!act[k] || (c % (int)G) != (int)blockIdx.x) continue;
+            reinterpret_cast<double2*>(f.p_new)[c] = vv[k];
+            double2 wk = make_double2(0.0, 0.0);
+            if (f.j > 1) wk = reinterpret_cast<const double2*>(f.w)[c];
+            const double2 lo = reinterpret_cast<const double2*>(f.wl)[c], hi = reinterpret_cast<const double2*>(f.wu)[c];
+            OpMinNan opmin;
+            double gm = f2b_term(vv[k].x, wk.x, lo.x, hi.x, f.atol_f2b);
+            if (2 * c + 1 < f.n) gm = opmin(gm, f2b_term(vv[k].y, wk.y, lo.y, hi.y, f.atol_f2b));
+            f.gpart[c] = gm;
+        }
+    }
+    if (VL && MODE != MODE_JTV) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) v_lds[k * T + tid] = vv[k];     // read back only by this lane
+    }
+
     if (!PF) {
         for (; g < ngroups; g += G) {
             load_group(A, g);
             process(A, g);
         }
     } else if (g < ngroups) {
-        load_group(A, g);
         while (true) {
             int64_t gn = g + G;
             if (gn < ngroups) load_group(B, gn);
@@ -193,6 +301,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
             if (act[k]) out[tid + k * T] = zz[k];
+        if (CGP && tid == 0) a.cf.sqpart[blockIdx.x] = sq_acc;
     }
 }
 

@@ -94,7 +94,25 @@ struct CgState {
     int margin_at;       // ... at which H*p product
     int tie_flags;       // TIE_* bits of the tests that came within kTieRel of their threshold
     int tie_first;       // first H*p product at which that happened (0: never)
+    // Two-kernel box iteration (bh_cgfuse.hip.h): the iteration at which the loop stopped (0: still running).  Kernels of
+    // iteration j > stop_at return at once; kernels of iteration j == stop_at never look at a word their own launch writes.
+    int stop_at;
+    int pad2;
 };
+
+// Sum / min of m doubles by ONE wave in an order that does not depend on the workgroup shape: lane l folds x[l], x[l+64], ...
+// in index order, then the fixed butterfly.  Every wave (of any kernel) that calls it on the same data gets the same bits.
+__device__ __forceinline__ double wave_fixed_sum(const double* __restrict__ x, int m) {
+    double acc = 0.0;
+    for (int i = threadIdx.x & 63; i < m; i += 64) acc += x[i];
+    return wave_sum(acc);
+}
+__device__ __forceinline__ double wave_fixed_min(const double* __restrict__ x, int m) {
+    OpMinNan op;
+    double acc = __longlong_as_double(0x7ff0000000000000ll);
+    for (int i = threadIdx.x & 63; i < m; i += 64) acc = op(acc, x[i]);
+    return wave_min(acc);
+}
 
 // Branch tests of projected_cg whose outcome can flip under rounding (src/basic_tralcnlss.jl:725, :727, :735, :747).
 enum { TIE_NEGCURV = 1, TIE_NEGCURV_ABS = 2, TIE_BOUND = 4, TIE_TOL = 8 };
