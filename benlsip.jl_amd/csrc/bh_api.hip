@@ -1754,6 +1754,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         const int nblk = (H->nchunks + 15) / 16;
         double* pbuf[2] = {c.p, c.p2};
         double* rvbuf[2] = {c.rvpart, c.rvpart + n_pad / 2};
+        int expect_stop_at = H->last_n_hmul > 0 ? H->last_n_hmul + 1 : 0;     // the launch expected to find the loop finished
         auto launch_stream = [&](int j) -> int32_t {            // H*p of iteration j (1-based), p_j formed on the fly
             RowStreamArgs ra = rs_args(H, nrows, nullptr);
             ra.partials = H->partials;
@@ -1764,7 +1765,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nblk;
             f.w = wp; f.wl = wlp; f.wu = wup;
             f.sqpart = H->sq_partials; f.gpart = c.gpart;
-            f.kappa2 = kappa2; f.atol_f2b = atol_f2b;
+            f.kappa2 = kappa2; f.atol_f2b = atol_f2b; f.expect_stop = (j == expect_stop_at || j > max_iter) ? 1 : 0;
             f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
             int slot = -1;
             BH_TRY(profile_begin(H, j - 1, &slot));

@@ -27,7 +27,7 @@ struct CgUpdArgs {
     int j;                          // iteration (1-based) = number of the H*p product being consumed
     const double* partials; int64_t ld; int nchunks; int G;      // slabs of the preceding row_stream launch
     const double* sqpart;           // [G]
-    const double* gpart;            // [nchunks]
+    const double* gpart;            // [G]
     const double* rvpart_in;        // [nrv] partials of r.v from iteration j-1   (j >= 2)
     double* rvpart_out;             // [gridDim.x]
     int nrv;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
 
     // ---- the iteration's scalars, recomputed by every wave from the partials (identical bits everywhere) -----------------
     const double pHp = wave_fixed_sum(a.sqpart, a.G);                                  // :723
-    const double gamma = wave_fixed_min(a.gpart, a.nchunks);                           // :728 / :734
+    const double gamma = wave_fixed_min(a.gpart, a.G);                                 // :728 / :734
     const double rtv = (a.j == 1) ? st->rtv : wave_fixed_sum(a.rvpart_in, a.nrv);      // :732  (j == 1: written by the H*p launch)
     int cont = 0, neg = 0, outside = 0;
     double step = 0.0, alpha = QNAN;
@@ -101,26 +101,25 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
         double2 hp = sm[0][cl];
 #pragma unroll
         for (int q = 1; q < 16; ++q) { hp.x += sm[q][cl].x; hp.y += sm[q][cl].y; }
-        const bool full = (2 * c + 1) < a.n;
+        // Every vector here is either the caller's buffer with n == 2*nchunks or a zero-padded workspace vector: whole 16-byte
+        // chunks are always addressable.  Elements at or beyond n are kept at exactly 0 (never updated: Inf*0 would poison them).
+        const bool e0 = 2 * c < a.n, e1 = 2 * c + 1 < a.n;
         const double2 pk = reinterpret_cast<const double2*>(a.p)[c];
         double2 wk = make_double2(0.0, 0.0), hwk = make_double2(0.0, 0.0), rk;
         if (a.j == 1) {
-            rk = reinterpret_cast<const double2*>(a.g)[c];
-            if (!full) rk.y = 0.0;                                   // odd n: never trust the element past the end
+            rk = reinterpret_cast<const double2*>(a.g)[c];           // r = g_minor (:705), w = 0 (:702)
         } else {
             rk = reinterpret_cast<const double2*>(a.r)[c];
-            if (full) wk = reinterpret_cast<const double2*>(a.w)[c]; else wk.x = a.w[2 * c];
-            if (a.hw != nullptr) { if (full) hwk = reinterpret_cast<const double2*>(a.hw)[c]; else hwk.x = a.hw[2 * c]; }
+            wk = reinterpret_cast<const double2*>(a.w)[c];
+            if (a.hw != nullptr) hwk = reinterpret_cast<const double2*>(a.hw)[c];
         }
         int2 fr = make_int2(-1, -1);
         if (a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[c];
         if (add_w) {
             wk.x = __dadd_rn(wk.x, __dmul_rn(step, pk.x));           // :729 / :737 / :739
+            wk.y = __dadd_rn(wk.y, __dmul_rn(step, pk.y));
             hwk.x = __dadd_rn(hwk.x, __dmul_rn(step, hp.x));
-            if (full) {
-                wk.y = __dadd_rn(wk.y, __dmul_rn(step, pk.y));
-                hwk.y = __dadd_rn(hwk.y, __dmul_rn(step, hp.y));
-            }
+            hwk.y = __dadd_rn(hwk.y, __dmul_rn(step, hp.y));
         }
         double2 vk = make_double2(0.0, 0.0);
         if (cont) {
@@ -128,16 +127,17 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
             rk.y = __dadd_rn(rk.y, __dmul_rn(alpha, hp.y));
             vk.x = (fr.x >= 0) ? 0.0 : rk.x;                         // projection!, box case (:741)
             vk.y = (fr.y >= 0) ? 0.0 : rk.y;
-            rv_part = fma(rk.y, vk.y, rk.x * vk.x);                  // :743 (this chunk)
         }
-        // stores: never beyond n (w += Inf*0 would poison the padding)
+        if (!e0) { wk.x = 0.0; hwk.x = 0.0; rk.x = 0.0; vk.x = 0.0; }
+        if (!e1) { wk.y = 0.0; hwk.y = 0.0; rk.y = 0.0; vk.y = 0.0; }
+        if (cont) rv_part = fma(rk.y, vk.y, rk.x * vk.x);            // :743 (this chunk)
         if (add_w || a.j == 1) {
-            if (full) reinterpret_cast<double2*>(a.w)[c] = wk; else a.w[2 * c] = wk.x;
-            if (a.hw != nullptr) { if (full) reinterpret_cast<double2*>(a.hw)[c] = hwk; else a.hw[2 * c] = hwk.x; }
+            reinterpret_cast<double2*>(a.w)[c] = wk;
+            if (a.hw != nullptr) reinterpret_cast<double2*>(a.hw)[c] = hwk;
         }
         if (cont || a.j == 1) {
-            if (full) { reinterpret_cast<double2*>(a.r)[c] = rk; reinterpret_cast<double2*>(a.v)[c] = vk; }
-            else { a.r[2 * c] = rk.x; a.v[2 * c] = vk.x; }
+            reinterpret_cast<double2*>(a.r)[c] = rk;
+            reinterpret_cast<double2*>(a.v)[c] = vk;
         }
     }
     if (rl == 0) rvs[cl] = rv_part;

@@ -31,7 +31,8 @@ struct CgFuse {
     const double* w;        // w after iteration j-1 (j == 1: w = 0)
     const double* wl; const double* wu;
     double* sqpart;         // [gridDim.x]  sum over this workgroup's rows of weight_i * (J p)_i^2   ->  pHp
-    double* gpart;          // [nchunks]    factor_to_boundary terms of p_j, per chunk               ->  gamma
+    double* gpart;          // [gridDim.x]  min of the factor_to_boundary terms of the chunks this workgroup owns   ->  gamma
+    int expect_stop;        // host hint: this launch is expected to find the loop finished (do not prefetch J before the exit test)
     double kappa2, atol_f2b;
     double* trace; int trace_cap;
     unsigned long long* mirror; unsigned tag;
@@ -178,21 +179,25 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     };
 
     int64_t g = blockIdx.x;
-    // the first row group does not depend on the vector: its loads go out before the vector (or the CG prologue) is touched
-    if (PF && g < ngroups) load_group(A, g);
-
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
-        const int c = tid + k * T;
         vv[k] = make_double2(0.0, 0.0);
         zz[k] = make_double2(0.0, 0.0);
-        if (MODE != MODE_JTV && act[k] && !(CGP && a.cf.j > 1)) {
-            vv[k] = reinterpret_cast<const double2*>(a.v)[c];
-            if (a.negate) {
-                int2 f = make_int2(-1, -1);
-                if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
-                vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
-                vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
+    }
+    if (!CGP || a.cf.j == 1) {
+        // the first row group does not depend on the vector: its loads go out first
+        if (PF && g < ngroups) load_group(A, g);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + k * T;
+            if (MODE != MODE_JTV && act[k]) {
+                vv[k] = reinterpret_cast<const double2*>(a.v)[c];
+                if (a.negate) {
+                    int2 f = make_int2(-1, -1);
+                    if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
+                    vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
+                    vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
+                }
             }
         }
     }
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
             // projected_cg's initialisation (:702-718) belongs to workgroup 0: r = g, v = P(r) = mask(g), p = -v (formed above),
             // rtv = r.v, tol_cg = kappa2*||v||, iter = 1, all flags down
             if (blockIdx.x == 0) {
-                double rtv0 = 0.0, vv0 = 0.0;
+                double rtv0 = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {        // vv = -mask(g):  r.v = v.v = sum of squares of the free components
                     rtv0 = fma(vv[k].x, vv[k].x, rtv0); rtv0 = fma(vv[k].y, vv[k].y, rtv0);
@@ -214,19 +219,30 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 if (tid == 0) {
                     double t = 0.0;
                     for (int w2 = 0; w2 < NW; ++w2) t += pro[0][w2];
-                    vv0 = t;
                     st->rtv = t;                                   // :707  (r.v with v = mask(r))
-                    st->tol_cg = f.kappa2 * sqrt(vv0);             // :710
+                    st->tol_cg = f.kappa2 * sqrt(t);               // :710
                     st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
                     st->iter = 1; st->max_iter = f.max_iter;
                     st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
                     st->n_hmul = 0; st->need_proj = 0; st->done = 0; st->status = 4; st->stop_at = 0;
                     tie_reset(st);
                 }
+                __syncthreads();                                   // pro[] is reused below
             }
         } else {
+            // loads of the prologue first (they come back in ~1 us from L2), the first row group of J right behind them
+            double2 vk[CPT], po[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                vk[k] = po[k] = make_double2(0.0, 0.0);
+                if (act[k]) {
+                    vk[k] = reinterpret_cast<const double2*>(f.vvec)[tid + k * T];
+                    po[k] = reinterpret_cast<const double2*>(f.p_old)[tid + k * T];
+                }
+            }
             const double rtv_next = wave_fixed_sum(f.rvpart, f.nrv);          // :743, same bits in every wave of every workgroup
             const double rtv = st->rtv, tol_cg = st->tol_cg;
+            if (!f.expect_stop && PF && g < ngroups) load_group(A, g);
             const bool solved = fabs(rtv_next) < tol_cg;                       // :747
             const bool stop = solved || f.j > f.max_iter;                      // :720 with iter = j after :748
             const double beta = __ddiv_rn(rtv_next, rtv);                      // :744
@@ -244,17 +260,17 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 publish_state(pa, st);                 // "stopped after iteration j-1", or "iter = j: iteration j is streaming"
             }
             if (stop) return;
+            if (f.expect_stop && PF && g < ngroups) load_group(A, g);         // the hint was wrong: carry on
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
-                if (!act[k]) continue;
-                const int c = tid + k * T;
-                const double2 vk = reinterpret_cast<const double2*>(f.vvec)[c];
-                const double2 po = reinterpret_cast<const double2*>(f.p_old)[c];
-                vv[k].x = __dadd_rn(-vk.x, __dmul_rn(beta, po.x));             // :745
-                vv[k].y = __dadd_rn(-vk.y, __dmul_rn(beta, po.y));
+                vv[k].x = __dadd_rn(-vk[k].x, __dmul_rn(beta, po[k].x));       // :745
+                vv[k].y = __dadd_rn(-vk[k].y, __dmul_rn(beta, po[k].y));
             }
         }
-        // the chunks this workgroup owns: store p_j, and their factor_to_boundary terms (:734 / :728)
+        // the chunks this workgroup owns (chunk c belongs to workgroup c % gridDim.x): store p_j; the workgroup's share of
+        // gamma = factor_to_boundary(p, w, w_l, w_u) (:734 / :728)
+        OpMinNan opmin;
+        double gm = __longlong_as_double(0x7ff0000000000000ll);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int c = tid + k * T;
@@ -263,11 +279,17 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
             double2 wk = make_double2(0.0, 0.0);
             if (f.j > 1) wk = reinterpret_cast<const double2*>(f.w)[c];
             const double2 lo = reinterpret_cast<const double2*>(f.wl)[c], hi = reinterpret_cast<const double2*>(f.wu)[c];
-            OpMinNan opmin;
-            double gm = f2b_term(vv[k].x, wk.x, lo.x, hi.x, f.atol_f2b);
+            if (2 * c < f.n) gm = opmin(gm, f2b_term(vv[k].x, wk.x, lo.x, hi.x, f.atol_f2b));
             if (2 * c + 1 < f.n) gm = opmin(gm, f2b_term(vv[k].y, wk.y, lo.y, hi.y, f.atol_f2b));
-            f.gpart[c] = gm;
         }
+        gm = wave_min(gm);
+        if (NW > 1) {
+            if (lane == 0) pro[1][wave] = gm;
+            __syncthreads();
+            gm = pro[1][0];
+            for (int w2 = 1; w2 < NW; ++w2) gm = opmin(gm, pro[1][w2]);
+        }
+        if (tid == 0) f.gpart[blockIdx.x] = gm;
     }
     if (VL && MODE != MODE_JTV) {
 #pragma unroll
