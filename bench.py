@@ -73,9 +73,11 @@ def pmc_traffic():
     if not files:
         return None, None
     data = json.load(open(files[-1]))
-    for name, e in data.get("kernels", {}).items():
-        if "row_stream_kernel<256, 8, 4, 2" in name and "hbm_bytes_per_launch" in e:
-            return e["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    # the dominant kernel: the fused single-read J'(Jp) launch of the two-kernel CG iteration (CGP = 1), or its plain form
+    for key in ("row_stream_kernel<256, 8, 4, 2, 1, 1, 0, 1>", "row_stream_kernel<256, 8, 4, 2, 1, 1, 0>", "row_stream_kernel<256, 8, 4, 2"):
+        for name, e in data.get("kernels", {}).items():
+            if key in name and "hbm_bytes_per_launch" in e:
+                return e["hbm_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
     return None, None
 
 
@@ -312,7 +314,8 @@ def main():
         "cg_iters_per_s": (iters - 1) * args.steps / elapsed,
         "ms_per_cg_iteration": ms_per_step / max(n_hmul, 1),
         "roofline": {
-            "bound": "hbm", "kernel": "row_stream_kernel<256,8,4,MODE_FUSED,NT> (single-read J'(Jp), non-temporal loads)",
+            "bound": "hbm", "kernel": "row_stream_kernel<256,8,4,MODE_FUSED,NT,PF,VL=0,CGP=1> (single-read J'(Jp), non-temporal loads; "
+                                      "rocprofv3 name: row_stream_kernel<256, 8, 4, 2, 1, 1, 0, 1>)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "frac_of_guide_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic": traffic, "traffic_source": traffic_src,

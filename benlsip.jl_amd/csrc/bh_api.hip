@@ -240,10 +240,11 @@ void launch_rs_mode(int mode, const RowStreamArgs& a, int grid, hipStream_t s) {
     }
 }
 
-// MODE_FUSED with the CG prologue (two-kernel box iteration); default geometries only.
+// MODE_FUSED with the CG prologue (two-kernel box iteration); default geometries only.  CGP = 2: the launch expected to stop.
 template <int T, int CPT, int R>
-void launch_rs_cgp(const RowStreamArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 0, 1>), dim3(grid), dim3(T), 0, s, a);
+void launch_rs_cgp(const RowStreamArgs& a, int grid, hipStream_t s, bool expect_stop) {
+    if (expect_stop) hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 0, 2>), dim3(grid), dim3(T), 0, s, a);
+    else hipLaunchKernelGGL((row_stream_kernel<T, CPT, R, MODE_FUSED, 1, 1, 0, 1>), dim3(grid), dim3(T), 0, s, a);
 }
 
 // n <= 16384: J v and J'u keep everything in registers; the fused mode needs the v slice in LDS (T * CPT * 16 bytes = 128 KiB,
@@ -281,23 +282,26 @@ void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipS
 }
 
 bool cgp_supported(int cfg) { return cfg <= 5 || cfg == 14; }
-void launch_row_stream_cgp(int cfg, const RowStreamArgs& a, int grid, hipStream_t s) {
+void launch_row_stream_cgp(int cfg, const RowStreamArgs& a, int grid, hipStream_t s, bool expect_stop) {
     switch (cfg) {
-        case 0: launch_rs_cgp<64, 1, 8>(a, grid, s); break;
-        case 1: launch_rs_cgp<256, 1, 8>(a, grid, s); break;
-        case 2: launch_rs_cgp<256, 2, 8>(a, grid, s); break;
-        case 3: launch_rs_cgp<256, 4, 4>(a, grid, s); break;
-        case 4: launch_rs_cgp<256, 8, 4>(a, grid, s); break;
-        case 5: launch_rs_cgp<512, 8, 2>(a, grid, s); break;
+        case 0: launch_rs_cgp<64, 1, 8>(a, grid, s, expect_stop); break;
+        case 1: launch_rs_cgp<256, 1, 8>(a, grid, s, expect_stop); break;
+        case 2: launch_rs_cgp<256, 2, 8>(a, grid, s, expect_stop); break;
+        case 3: launch_rs_cgp<256, 4, 4>(a, grid, s, expect_stop); break;
+        case 4: launch_rs_cgp<256, 8, 4>(a, grid, s, expect_stop); break;
+        case 5: launch_rs_cgp<512, 8, 2>(a, grid, s, expect_stop); break;
         default: {
             constexpr size_t lds = (size_t)512 * 16 * sizeof(double2);
             static bool attr_set = false;      // (per process; bh_shutdown + bh_init keep the same code object)
             if (!attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_set = true;
             }
-            hipLaunchKernelGGL((row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>), dim3(grid), dim3(512), lds, s, a);
+            if (expect_stop) hipLaunchKernelGGL((row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 2>), dim3(grid), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>), dim3(grid), dim3(512), lds, s, a);
             break;
         }
     }
@@ -1765,11 +1769,11 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nblk;
             f.w = wp; f.wl = wlp; f.wu = wup;
             f.sqpart = H->sq_partials; f.gpart = c.gpart;
-            f.kappa2 = kappa2; f.atol_f2b = atol_f2b; f.expect_stop = (j == expect_stop_at || j > max_iter) ? 1 : 0;
+            f.kappa2 = kappa2; f.atol_f2b = atol_f2b;
             f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
             int slot = -1;
             BH_TRY(profile_begin(H, j - 1, &slot));
-            launch_row_stream_cgp(rs_cfg, ra, grid, s);
+            launch_row_stream_cgp(rs_cfg, ra, grid, s, j == expect_stop_at || j > max_iter);
             if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], s));
             return BH_OK;
         };

@@ -32,7 +32,6 @@ struct CgFuse {
     const double* wl; const double* wu;
     double* sqpart;         // [gridDim.x]  sum over this workgroup's rows of weight_i * (J p)_i^2   ->  pHp
     double* gpart;          // [gridDim.x]  min of the factor_to_boundary terms of the chunks this workgroup owns   ->  gamma
-    int expect_stop;        // host hint: this launch is expected to find the loop finished (do not prefetch J before the exit test)
     double kappa2, atol_f2b;
     double* trace; int trace_cap;
     unsigned long long* mirror; unsigned tag;
@@ -65,8 +64,11 @@ struct RowStreamArgs {
 // VL: 1 = each lane parks its slice of v in LDS (dynamic, nchunks x 16 bytes, lane-private slots: no barrier, no bank
 // conflicts) instead of registers.  For 8192 < n <= 16384 the two row buffers and the z accumulators of the fused mode
 // fill the register file on their own; the 128 KiB of LDS a CU has left over hold v.
-// CGP: 1 = MODE_FUSED launch of the two-kernel box CG iteration: the prologue below forms p_j (and the loop's exit test)
-// while the first row group is already on its way from HBM.
+// CGP: 1 = MODE_FUSED launch of the two-kernel box CG iteration: the prologue below forms p_j (and takes the loop's exit test)
+// while the first row group is already on its way from HBM.  2 = the same code as a SEPARATE symbol for the launch the host
+// expects to find the loop finished (its prediction: the previous call's iteration count): no prefetch before the exit test,
+// and — the reason for a symbol of its own — its ~2 us dispatches do not dilute the streaming kernel's per-kernel average in a
+// rocprofv3 --stats summary.  Either symbol does the right thing if the prediction is wrong.
 template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1, int VL = 0, int CGP = 0>
 __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     if (!CGP && a.state != nullptr && a.state->done) return;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
             }
             const double rtv_next = wave_fixed_sum(f.rvpart, f.nrv);          // :743, same bits in every wave of every workgroup
             const double rtv = st->rtv, tol_cg = st->tol_cg;
-            if (!f.expect_stop && PF && g < ngroups) load_group(A, g);
+            if (CGP != 2 && PF && g < ngroups) load_group(A, g);
             const bool solved = fabs(rtv_next) < tol_cg;                       // :747
             const bool stop = solved || f.j > f.max_iter;                      // :720 with iter = j after :748
             const double beta = __ddiv_rn(rtv_next, rtv);                      // :744
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 publish_state(pa, st);                 // "stopped after iteration j-1", or "iter = j: iteration j is streaming"
             }
             if (stop) return;
-            if (f.expect_stop && PF && g < ngroups) load_group(A, g);         // the hint was wrong: carry on
+            if (CGP == 2 && PF && g < ngroups) load_group(A, g);              // the prediction was wrong: carry on
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
                 vv[k].x = __dadd_rn(-vk[k].x, __dmul_rn(beta, po[k].x));       // :745
