@@ -289,6 +289,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        (needs the caller's factor in bh_proj_set_active)
  *   "pcg_batch"      [0] CG iterations enqueued per launch-ahead batch; 0 = by problem size (1 when an H*p streams >= 100 us)
  *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
+ *   "cg_fused"       [1] box constraints on one rank: two kernels per CG iteration (the H*p launch forms p and takes the exit test,
+ *                        one kernel reduces the slabs and updates w, r, v) instead of three (H*p, slab reduction, step kernel)
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2), faster, errors accumulate)

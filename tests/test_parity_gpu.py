@@ -278,7 +278,16 @@ def _load_case(c):
     return J, C, A, L, fix, _flt(c["g"]), _flt(c["w_l"]), _flt(c["w_u"])
 
 
-def test_pcg_golden_fixtures(bh):
+@pytest.fixture(params=[1, 0], ids=["two_kernel_iteration", "three_kernel_iteration"])
+def cg_fused(request, bh):
+    """Both shapes of the box-constrained CG iteration: H*p with the p-update folded in + one reduce/update kernel (default),
+    and H*p + slab reduction + single-workgroup step kernel (what multi-rank runs and A/B geometries use)."""
+    bh.set_option("cg_fused", request.param)
+    yield request.param
+    bh.set_option("cg_fused", 1)
+
+
+def test_pcg_golden_fixtures(bh, cg_fused):
     """Committed oracle fixtures: every reachable exit status, q>0, mA>0, p>0, odd n, n=3, max_iter=0, exhaustion."""
     cases = json.load(open(os.path.join(GOLD, "pcg_cases.json")))["cases"]
     for c in cases:
@@ -311,7 +320,7 @@ def test_pcg_golden_fixtures(bh):
 
 @pytest.mark.parametrize("d,n,q,mA,nfix,seed", [(50, 20, 0, 0, 4, 1), (200, 64, 1, 3, 10, 2), (300, 100, 0, 0, 0, 3), (512, 257, 0, 2, 30, 4),
                                                 (1024, 512, 0, 0, 64, 5), (2000, 1000, 2, 8, 100, 6), (600, 300, 0, 16, 0, 7)])
-def test_pcg_random_instances(bh, d, n, q, mA, nfix, seed):
+def test_pcg_random_instances(bh, cg_fused, d, n, q, mA, nfix, seed):
     rng = np.random.default_rng(seed)
     J = rng.standard_normal((d, n)) / np.sqrt(d)
     C = rng.standard_normal((q, n))
@@ -580,7 +589,7 @@ print("OK", a[2], a[3])
     assert out.stdout.strip().splitlines()[-1].startswith("OK")
 
 
-def test_workspace_reuse_across_sizes_and_odd_n(bh):
+def test_workspace_reuse_across_sizes_and_odd_n(bh, cg_fused):
     """The CG workspace is shared by all calls: a larger problem must not leak into the padding of a later smaller / odd-n
     one (box and general path)."""
     rng = np.random.default_rng(42)

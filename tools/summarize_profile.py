@@ -34,7 +34,9 @@ def main(tag):
         for name, vals in acc.items():
             # a launch enqueued past the CG exit sees state->done and returns at once (a gated no-op, ~0 bytes): it is a
             # dispatch of the same kernel symbol but not a launch of the operation, so it must not dilute the average
-            live = [v for v in vals if v >= 0.01 * max(vals)] if max(vals) > 0 else vals
+            # (the two-kernel CG iteration adds a second kind: a launch whose prologue finds the loop finished after it has
+            # prefetched one row group — 32 MiB instead of 2 GiB; rare, on a fresh handle without an iteration-count hint)
+            live = [v for v in vals if v >= 0.5 * max(vals)] if max(vals) > 0 else vals
             pmc.setdefault(name, {})[counter + "_KiB_avg"] = sum(live) / len(live)
             pmc[name][counter + "_dispatches"] = len(live)
             pmc[name][counter + "_gated_dispatches_excluded"] = len(vals) - len(live)
