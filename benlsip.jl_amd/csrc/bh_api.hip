@@ -121,6 +121,13 @@ struct Ctx {
     int comm_path = 0;
     CgWorkspace cg;
     double* scratch_dev = nullptr;   // small device scratch (selftest, f2b)
+    // Jacobian images of destroyed handles, kept for the next bh_hess_create* of a similar size: the reference builds a new
+    // AlHessian for every accepted step (src/basic_tralcnlss.jl:361-362) and drops the old one — a 2 GiB hipFree makes the
+    // driver scrub the memory in the background (-5 % HBM bandwidth for ~60 ms) and the next hipMalloc costs ~4 ms
+    struct PooledImage { double* ptr; int64_t doubles; };
+    std::vector<PooledImage> image_pool;
+    int64_t opt_image_pool = 2;      // images kept (0: free at once)
+    int64_t image_pool_hits = 0;
     AsyncUpload* upload_cache = nullptr;   // streams, events and staging buffers of the last finished asynchronous upload, kept for the next
     // host <-> device traffic issued by the library since bh_init (bh_stats: the device-resident entry points are checked against it)
     int64_t h2d_bytes = 0, d2h_bytes = 0, h2d_calls = 0, d2h_calls = 0;
@@ -330,6 +337,7 @@ struct bh_hess {
     int nchunks = 0;
     double mu = 0.0;
     double* Jd = nullptr;          // (d + q) x ld row-major
+    int64_t Jd_doubles = 0;        // capacity of the allocation behind Jd (it may come from the image pool)
     double* vpad = nullptr;        // ld
     double* zpad = nullptr;        // ld
     double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
@@ -618,7 +626,23 @@ int32_t alloc_hess_common(bh_hess* H) {
     H->ld = round_up(std::max<int64_t>(H->n, 1), 16);
     H->nchunks = (int)(H->ld / 2);
     H->q_eff = (g_ctx.rank == 0) ? H->q : 0;   // C is replicated: only rank 0 contributes C'(mu C v)
-    BH_TRY(dev_alloc(&H->Jd, std::max<int64_t>(rows, 1) * H->ld));
+    {   // the image: from the pool when a retired one fits (>= the size needed, <= twice)
+        const int64_t need = std::max<int64_t>(rows, 1) * H->ld;
+        int best = -1;
+        for (int i = 0; i < (int)g_ctx.image_pool.size(); ++i) {
+            const int64_t have = g_ctx.image_pool[(size_t)i].doubles;
+            if (have >= need && have <= 2 * need && (best < 0 || have < g_ctx.image_pool[(size_t)best].doubles)) best = i;
+        }
+        if (best >= 0) {
+            H->Jd = g_ctx.image_pool[(size_t)best].ptr;
+            H->Jd_doubles = g_ctx.image_pool[(size_t)best].doubles;
+            g_ctx.image_pool.erase(g_ctx.image_pool.begin() + best);
+            g_ctx.image_pool_hits += 1;
+        } else {
+            BH_TRY(dev_alloc(&H->Jd, need));
+            H->Jd_doubles = need;
+        }
+    }
     BH_TRY(dev_alloc(&H->vpad, H->ld));
     BH_TRY(dev_alloc(&H->zpad, H->ld));
     BH_TRY(dev_alloc(&H->upad, std::max<int64_t>(rows, 1)));
@@ -1043,6 +1067,8 @@ int32_t bh_shutdown(void) {
     dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
     dev_free(g_ctx.rbuf); g_ctx.rbuf = nullptr; g_ctx.rbuf_cap = 0;
     async_upload_destroy(g_ctx.upload_cache); g_ctx.upload_cache = nullptr;
+    for (auto& im : g_ctx.image_pool) dev_free(im.ptr);
+    g_ctx.image_pool.clear();
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
     g_ctx.own_stream = nullptr; g_ctx.stream = nullptr;
     if (g_pin.base) { (void)hipHostFree(g_pin.base); g_pin = PinArena(); }
@@ -1091,6 +1117,12 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "image_pool")) {
+        if (value < 0 || value > 8) return fail(BH_ERR_INVALID_ARG, "image_pool must be 0..8");
+        g_ctx.opt_image_pool = value;
+        while ((int64_t)g_ctx.image_pool.size() > value) { dev_free(g_ctx.image_pool.back().ptr); g_ctx.image_pool.pop_back(); }
+        return BH_OK;
+    }
     if (!strcmp(key, "upload_chunk_mb")) {
         if (value < 1 || value > 4096) return fail(BH_ERR_INVALID_ARG, "upload_chunk_mb must be 1..4096");
         g_ctx.opt_upload_chunk_mb = value;
@@ -1471,7 +1503,12 @@ int32_t bh_hess_destroy(bh_hess* H) {
     }
     if (H->counted) g_ctx.live_hess -= 1;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
-    dev_free(H->Jd); dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf);
+    if (H->Jd && g_ctx.init && (int64_t)g_ctx.image_pool.size() < g_ctx.opt_image_pool && H->Jd_doubles >= (1 << 17)) {
+        g_ctx.image_pool.push_back({H->Jd, H->Jd_doubles});       // >= 1 MiB images only: small ones are not worth a pool slot
+    } else {
+        dev_free(H->Jd);
+    }
+    dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf);
     dev_free(H->partials); dev_free(H->sq_partials); dev_free(H->scalar);
     for (auto e : H->ev) if (e) (void)hipEventDestroy(e);
     delete H;

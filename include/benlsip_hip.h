@@ -303,6 +303,9 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "comm_path"      [0 with BH_COMM=rccl|both, 1 with BH_COMM=ipc] which communicator carries the all-reduces: 0 = RCCL,
  *                        1 = the one-shot peer-buffer exchange fused into the slab reduction (needs BH_COMM=ipc or both)
  *   "profile"        [flags of bh_init] 1 = hipEvents around every profile_stride-th H*p launch (bh_stats: hmul_ms / hmul_timed)
+ *   "image_pool"     [2] Jacobian images of destroyed handles kept for the next bh_hess_create* of a similar size (0..8; 0 frees at
+ *                        once).  The reference builds a new AlHessian per accepted step and drops the old one: recycling the
+ *                        2 GiB image avoids the driver's background scrub of freed VRAM and a ~4 ms hipMalloc per step.
  *   "upload_chunk_mb" [64] bh_hess_create_async: MiB of J per pipelined column chunk (1..4096)
  *   "profile_stride" [8] >= 1; an event pair costs ~10 us of stream time, so 1 is for short runs only (at most 512 samples per call) */
 int32_t bh_set_option(const char* key, int64_t value);

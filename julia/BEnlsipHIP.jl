@@ -6,6 +6,13 @@
 #   BEnlsipHIP.init()                       # once per process (one process per GPU)
 #   x, y = tralcnllss(x0, r, jac_r, c, jac_c, A, b, x_l, x_u)   # unchanged outer iteration
 #
+# What it shadows (all Float64 methods next to the package's parametric ones):
+#   hot path          Base.:*(H, v), vthv, projection!, projected_cg                         (src/basic_tralcnlss.jl:92-106, :690-764; poly:158-170)
+#   callers           minor_iterate, cauchy_step; opt-in: inner_step with device-resident vectors (:394-460, :574-675)
+#   row-shard seams   new_point, evaluate_al, first_derivatives (+ second_derivatives), least_squares_multipliers
+#                     (:32-85, :887-903): mx and g all-reduced so that a multi-rank run stays in lock-step
+#   opt-in            update_chol! (skip the host factor), reference_projection_form!
+#
 # STATUS: written against the reference at /root/reference and syntax-reviewed only.  No Julia toolchain exists in
 # the build image or on the GPU box, so this file has never been executed there; the executable stand-in is the
 # Python mirror benlsip.jl_amd/operators.py driving the same C ABI (tests/test_parity_gpu.py).
@@ -88,8 +95,9 @@ function handle(lincons::BEnlsip.MixedConstraints{Float64})
     # cholesky_aug_aat has uplo == 'L' (factors = L), the initial cholesky(A*A') has uplo == 'U' (SURVEY.md §0.3-15).
     mA, n = size(lincons.lineq)
     mpp = mA + count(lincons.fixvars)
-    if SKIP_HOST_FACTOR[]
-        # reduced form: the factor argument is optional (lincons.chol may be stale, see skip_host_factor!)
+    if !REFERENCE_PROJECTION_FORM[]
+        # library default (reduced form): the device factors A_free*A_free' itself, so only the BitVector image travels
+        # (n/8 bytes; an identical push is recognised by the library and costs nothing) — lincons.chol is never read
         check(ccall((:bh_proj_set_active, libbh), Int32,
                     (Ptr{Cvoid}, Ptr{UInt64}, Int64, Ptr{Float64}, Int64, Int64),
                     h.ptr, lincons.fixvars.chunks, n, C_NULL, mpp, max(mpp, 1)), "bh_proj_set_active")
@@ -256,6 +264,16 @@ end
 #     BEnlsipHIP.skip_host_factor!(true)
 const SKIP_HOST_FACTOR = Ref(false)
 skip_host_factor!(flag::Bool = true) = (SKIP_HOST_FACTOR[] = flag)
+
+# The reference's augmented (mA+p) x (mA+p) projection form on the device (bh_set_option("proj_form", 0)): the caller's factor
+# lincons.chol is then pushed with every active-set change (8*mpp^2 bytes over PCIe) and must be kept up to date on the host
+# (incompatible with skip_host_factor!).  Off by default: the reduced form computes the same projector (DESIGN.md §4).
+const REFERENCE_PROJECTION_FORM = Ref(false)
+function reference_projection_form!(flag::Bool = true)
+    flag && SKIP_HOST_FACTOR[] && error("reference_projection_form! needs the host factor: call skip_host_factor!(false) first")
+    check(ccall((:bh_set_option, libbh), Int32, (Cstring, Int64), "proj_form", flag ? 0 : 1), "bh_set_option(proj_form)")
+    REFERENCE_PROJECTION_FORM[] = flag
+end
 
 function BEnlsip.update_chol!(lincons::BEnlsip.MixedConstraints{Float64}, chol_aat::Cholesky{Float64,Matrix{Float64}})
     if SKIP_HOST_FACTOR[]
