@@ -346,6 +346,10 @@ def main():
                     bh.set_option("comm_path", 0)
         except bh.BenlsipHipError as e:
             comm["error"] = str(e)
+            try:
+                bh.set_option("comm_path", 0)       # a timed-out peer exchange: back to RCCL for the rest of the run
+            except bh.BenlsipHipError:
+                pass
         comm["allreduce_us"] = comm.get("rccl_allreduce_us", comm.get("peer_allreduce_us"))
         line["comm"] = comm
         line["allreduce_us"] = comm["allreduce_us"]

@@ -54,6 +54,7 @@ struct PeerShm {
 };
 struct PeerComm {
     bool active = false;
+    bool broken = false;                     // an exchange timed out: the path may not be selected again
     void* inbox = nullptr;                   // slots | flags | seq, arrive   (one allocation: one IPC handle)
     size_t inbox_bytes = 0;
     void* peer_base[kMaxPeers] = {};         // mapped inboxes (own rank: inbox)
@@ -1138,6 +1139,13 @@ int32_t bh_set_option(const char* key, int64_t value) {
         if (value == 0 && comm_active() && g_ctx.comm == nullptr) return fail(BH_ERR_PRECONDITION, "comm_path = 0 needs an RCCL communicator (BH_COMM=rccl or both)");
         if (value != 0 && value != 1) return fail(BH_ERR_INVALID_ARG, "comm_path is 0 (RCCL) or 1 (peer buffers)");
         if (g_ctx.stream) (void)hipStreamSynchronize(g_ctx.stream);
+        // leaving the peer-buffer path after a timed-out exchange: the error word is cleared so that the RCCL path can carry on
+        // (re-selecting the peer path after a timeout is refused: the ranks' exchange counters no longer agree)
+        if (value == 0 && g_ctx.peer.active && g_ctx.peer.h_err != nullptr && *g_ctx.peer.h_err != 0ull) {
+            *g_ctx.peer.h_err = 0ull;
+            g_ctx.peer.broken = true;
+        }
+        if (value == 1 && g_ctx.peer.broken) return fail(BH_ERR_RCCL, "the peer-buffer transport timed out earlier in this communicator's life");
         g_ctx.comm_path = (int)value;
         return BH_OK;
     }

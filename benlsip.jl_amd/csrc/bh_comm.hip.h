@@ -118,7 +118,11 @@ __global__ __launch_bounds__(256) void reduce_exchange_kernel(const double* __re
     if (rl < pa.nranks && cl == 0) {
         const unsigned long long* f = pa.flags[pa.rank] + ((int64_t)par * kMaxPeers + rl) * pa.nblk_cap + blockIdx.x;
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        // once an exchange has timed out the transport is considered dead: later exchanges do not wait again (the host has
+        // been told through *pa.err and fails every call until the peer path is switched off)
+        const bool dead = __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+        if (dead) s_timeout = 1;
+        while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > pa.timeout_ticks) {     // a peer never arrived: report, never hang the device
                 s_timeout = 1;

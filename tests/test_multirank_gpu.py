@@ -192,3 +192,24 @@ def test_launch_schedule_is_rank_independent_at_a_batch_threshold(tmp_path):
         assert np.array_equal(res[0]["w"], res[r]["w"]) and int(res[0]["n_allreduce"]) == int(res[r]["n_allreduce"])
         assert int(res[0]["iters"]) == int(res[r]["iters"]) and int(res[0]["status"]) == int(res[r]["status"])
     assert int(res[0]["n_hmul"]) >= 10
+
+
+def test_peer_exchange_times_out_instead_of_hanging(tmp_path):
+    """A rank that never joins an exchange must not hang its peers' GPU: the waiting workgroups give up after
+    BH_PEER_TIMEOUT_S, the result is poisoned with NaN and the call returns BH_ERR_RCCL."""
+    world = 2
+    env, _ = comm_env("ipc")
+    env["BH_PEER_TIMEOUT_S"] = "2"
+    procs = [subprocess.Popen([sys.executable, os.path.join(MR, "timeout_worker.py"), str(r), str(world), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-2000:])
+    z0, z1 = (np.load(os.path.join(tmp_path, "to_rank%d.npz" % r)) for r in range(world))
+    assert np.array_equal(z0["a"], z1["a"])                       # the matched exchange worked
+    assert str(z0["outcome"]).startswith("error %d" % int(z0["code_rccl"])), str(z0["outcome"])
