@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <string>
 #include <thread>
 #include <vector>
@@ -387,7 +388,8 @@ namespace {
 int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
     CgWorkspace& c = g_ctx.cg;
     if (c.n_pad < n_pad) {
-        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.g, &c.wl, &c.wu, &c.x, &c.s, &c.xlow, &c.xupp, &c.hw, &c.p2, &c.gpart, &c.rvpart};
+        // order matters: the host-pointer entry points stage (g, wl, wu), (s, x, xlow, xupp, g) or (x, xlow, xupp, g) with ONE DMA
+        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.s, &c.x, &c.xlow, &c.xupp, &c.g, &c.wl, &c.wu, &c.hw, &c.p2, &c.gpart, &c.rvpart};
         constexpr int NV = 16;
         dev_free(c.slab);
         c.slab = nullptr;
@@ -824,6 +826,31 @@ int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_dev
     }
     BH_HIP(hipMemcpyAsync(dst_pad, src, (size_t)n * sizeof(double), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           g_ctx.stream));
+    return BH_OK;
+}
+
+// Several host vectors into CONSECUTIVE workspace vectors (stride n_pad) with one DMA instead of one each: a 32 KiB
+// hipMemcpyAsync costs ~10 us of stream time whatever its size, and the host-pointer entry points stage 3-5 of them.
+int32_t stage_vecs(double* dst_first, std::initializer_list<const double*> srcs, int64_t n, int64_t n_pad) {
+    const int64_t k = (int64_t)srcs.size();
+    double* pin = (n > 0) ? pin_alloc(k * n_pad) : nullptr;
+    if (pin == nullptr) {
+        int64_t i = 0;
+        for (const double* src : srcs) {       // too large for the arena: one copy each; the padding is zeroed as the batched path does
+            BH_TRY(stage_vec(dst_first + i * n_pad, src, n, false));
+            if (n_pad > n) BH_HIP(hipMemsetAsync(dst_first + i * n_pad + n, 0, (size_t)(n_pad - n) * sizeof(double), g_ctx.stream));
+            ++i;
+        }
+        return BH_OK;
+    }
+    int64_t i = 0;
+    for (const double* src : srcs) {
+        memcpy(pin + i * n_pad, src, (size_t)n * sizeof(double));
+        if (n_pad > n) memset(pin + i * n_pad + n, 0, (size_t)(n_pad - n) * sizeof(double));
+        ++i;
+    }
+    count_h2d((size_t)k * n * sizeof(double));
+    BH_HIP(hipMemcpyAsync(dst_first, pin, (size_t)(k * n_pad) * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
     return BH_OK;
 }
 
@@ -1769,7 +1796,8 @@ constexpr int kFirstBatchCapRccl = 8;
 // Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
 // still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
 static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* wlp, const double* wup, double* wp, bool w_in_ws,
-                       double kappa2, double atol_negcurv, double atol_f2b, int64_t trace_cap, PcgFin* fin_out, double* hw = nullptr) {
+                       double kappa2, double atol_negcurv, double atol_f2b, int64_t trace_cap, PcgFin* fin_out, double* hw = nullptr,
+                       bool g_pad_zeroed = false /* the staged copy of g arrived with its padding already zero */) {
     const int64_t n = H->n, n_pad = H->ld;
     const int64_t max_iter64 = 2 * (n - P->mA - P->nfix);   // src/basic_tralcnlss.jl:714
     if (max_iter64 < 0) return fail(BH_ERR_PRECONDITION, "n - mA - count(fixvars) < 0");
@@ -1797,7 +1825,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     const int rs_cfg = multi_panel(H) ? -1 : pick_config(H->nchunks);
     if (box && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && !comm_active() && max_iter >= 1 && (gp == c.g || n == n_pad)) {
         BH_TRY(hess_ready(H));
-        if (gp == c.g && n < n_pad) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
+        if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
         const int64_t nrows = H->d + H->q_eff;
         const int grid = grid_for(rs_cfg, nrows);
         const int nblk = (H->nchunks + 15) / 16;
@@ -1872,7 +1900,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     const bool fold_init = box && !multi_panel(H) && ((n + 1) / 2 <= 4 * CG_T) && max_iter >= 1 && g_ctx.opt_fold_init &&
                            (gp == c.g || n == n_pad);
     if (fold_init) {
-        if (gp == c.g && n < n_pad)   // stale padding of the staged g would be multiplied into the dot products
+        if (gp == c.g && n < n_pad && !g_pad_zeroed)   // stale padding of the staged g would be multiplied into the dot products
             BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
     } else if (box) {
         hipLaunchKernelGGL((cg_init_kernel<true>), dim3(1), dim3(CG_T), 0, s, a);
@@ -1989,17 +2017,23 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     const double *gp = g_minor, *wlp = w_l, *wup = w_u;
     double* wp = w_out;
     if (!in_place) {
-        BH_TRY(stage_vec(c.g, g_minor, n, dev));
-        BH_TRY(stage_vec(c.wl, w_l, n, dev));
-        BH_TRY(stage_vec(c.wu, w_u, n, dev));
+        if (!dev) {
+            BH_TRY(stage_vecs(c.g, {g_minor, w_l, w_u}, n, c.n_pad));      // c.g, c.wl, c.wu are consecutive
+        } else {
+            BH_TRY(stage_vec(c.g, g_minor, n, true));
+            BH_TRY(stage_vec(c.wl, w_l, n, true));
+            BH_TRY(stage_vec(c.wu, w_u, n, true));
+        }
         gp = c.g; wlp = c.wl; wup = c.wu; wp = c.w;
     }
     PcgFin fin{};
-    BH_TRY(pcg_run(H, P, gp, wlp, wup, wp, !in_place, kappa2, atol_negcurv, atol_f2b, trace_cap, &fin));
+    BH_TRY(pcg_run(H, P, gp, wlp, wup, wp, !in_place, kappa2, atol_negcurv, atol_f2b, trace_cap, &fin, nullptr, !dev));
     if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
     if (trace_cap > 0) count_d2h((size_t)4 * trace_cap * sizeof(double));
     if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
-    BH_TRY(sync_flush());      // drains the over-launched no-op kernels; orders w for any consumer
+    // EXPERIMENT (BH_SKIP_FINAL_SYNC=1; A/B only): how much of a subproblem is the final hipStreamSynchronize?
+    static const bool skip_sync = getenv("BH_SKIP_FINAL_SYNC") != nullptr && atoi(getenv("BH_SKIP_FINAL_SYNC")) != 0;
+    if (!(skip_sync && in_place && trace_cap == 0)) BH_TRY(sync_flush());      // drains the over-launched no-op kernels; orders w for any consumer
     BH_TRY(pcg_finish(H, fin));
     if (status) *status = fin.status;
     if (iters) *iters = fin.iter;
@@ -2095,13 +2129,11 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
     // the zero-padded workspace vector the CG kernels read in 16-byte chunks
     const double *xp = x, *sp = s_vec, *lop = xlow, *upp = xupp;
     if (!dev) {
-        BH_TRY(stage_vec(c.x, x, n, false));
-        BH_TRY(stage_vec(c.s, s_vec, n, false));
-        BH_TRY(stage_vec(c.xlow, xlow, n, false));
-        BH_TRY(stage_vec(c.xupp, xupp, n, false));
+        BH_TRY(stage_vecs(c.s, {s_vec, x, xlow, xupp, g_model}, n, c.n_pad));      // c.s, c.x, c.xlow, c.xupp, c.g are consecutive
         xp = c.x; sp = c.s; lop = c.xlow; upp = c.xupp;
+    } else {
+        BH_TRY(stage_vec(c.g, g_model, n, true));
     }
-    BH_TRY(stage_vec(c.g, g_model, n, dev));
     const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
     hipLaunchKernelGGL(step_bounds_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, xp, sp, lop, upp,
                        P->nfix > 0 ? P->fixrank : (const int*)nullptr, delta, (int)n, c.wl, c.wu);
@@ -2109,7 +2141,7 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
     // ls_from_cg: the CG loop accumulates H*w next to w, so linesearch's w'Hw (vthv(H,w), :775) costs a dot product
     // instead of another sweep over J (-0.3 ms per minor iterate at config 3); mathematically identical, rounding ~1e-15.
     double* hw = g_ctx.opt_ls_from_cg ? c.hw : nullptr;
-    BH_TRY(pcg_run(H, P, c.g, c.wl, c.wu, c.w, true, kappa2, atol_negcurv, atol_f2b, 0, &fin, hw));
+    BH_TRY(pcg_run(H, P, c.g, c.wl, c.wu, c.w, true, kappa2, atol_negcurv, atol_f2b, 0, &fin, hw, !dev));
     double alpha = std::nan("");
     const bool do_ls = fin.status != BH_CG_NEGATIVE_CURVATURE;       // :669
     if (do_ls) {
@@ -2347,10 +2379,14 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         if (lds > kLdsPerCu) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
         BH_TRY(ensure_trsv_lds(lds));
     }
-    BH_TRY(stage_vec(c.x, x, n, dev));
-    BH_TRY(stage_vec(c.g, g, n, dev));
-    BH_TRY(stage_vec(c.xlow, xlow, n, dev));
-    BH_TRY(stage_vec(c.xupp, xupp, n, dev));
+    if (!dev) {
+        BH_TRY(stage_vecs(c.x, {x, xlow, xupp, g}, n, c.n_pad));                   // c.x, c.xlow, c.xupp, c.g are consecutive
+    } else {
+        BH_TRY(stage_vec(c.x, x, n, true));
+        BH_TRY(stage_vec(c.g, g, n, true));
+        BH_TRY(stage_vec(c.xlow, xlow, n, true));
+        BH_TRY(stage_vec(c.xupp, xupp, n, true));
+    }
 
     CauchyArgs a{};
     a.st = c.d_state; a.x = c.x; a.g = c.g; a.xlow = c.xlow; a.xupp = c.xupp;
