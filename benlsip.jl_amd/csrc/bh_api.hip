@@ -104,6 +104,7 @@ struct Ctx {
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
+    int64_t opt_final_sync = 0;      // bh_pcg_dev: always drain the stream before returning (1), or only when results may still be in flight (0)
     int64_t opt_cg_fused = 1;        // box CG: two kernels per iteration (H*p with the p-update folded in + reduce/update) instead of three
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
     int64_t opt_upload_chunk_mb = 64; // bh_hess_create_async: MiB of J per pipelined column chunk
@@ -352,6 +353,8 @@ struct bh_hess {
     // tie log of the previous projected_cg on this handle (bh_pcg_tie_info)
     int tie_flags = 0, tie_first = 0, margin_kind = 0, margin_at = 0;
     double min_margin = 0.0;
+    unsigned tie_tag = 0;          // tag of the call the log belongs to
+    bool tie_read = true;          // false: the words have not been fetched from the host-mapped page yet
     bh_stats_t stats{};
     std::vector<hipEvent_t> ev;    // 2*kEvCap, created lazily
     std::vector<int> ev_pending;   // launch index (within the running bh_pcg) of each recorded pair
@@ -1076,6 +1079,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_PROJ_FORM")) g_ctx.opt_proj_form = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_CG_FUSED")) g_ctx.opt_cg_fused = atoll(s) ? 1 : 0;
+    if (const char* s = getenv("BH_FINAL_SYNC")) g_ctx.opt_final_sync = atoll(s) ? 1 : 0;
     g_ctx.init = true;
     return BH_OK;
 }
@@ -1141,6 +1145,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cg_fused")) { g_ctx.opt_cg_fused = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "final_sync")) { g_ctx.opt_final_sync = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
@@ -1773,7 +1778,10 @@ int32_t bh_left_mul_tr(bh_proj* P, const double* y, double* out_n) {
 }
 
 // ---- projected_cg ---------------------------------------------------------------------------
-struct PcgFin { int done, status, iter, n_hmul; };
+// results_final: every kernel that writes w (or H*w) had COMPLETED before the launch that published `done` started (two-kernel
+// iteration, loop stopped by the exit test in an H*p launch's prologue: solved / iterations exhausted).  The device-pointer entry
+// point then returns without draining the stream: what is still in flight are prologue-only launches that write nothing.
+struct PcgFin { int done, status, iter, n_hmul; bool results_final = false; unsigned tag = 0; };
 
 // How many iterations the host enqueues per launch-ahead batch.  One batch is always in flight while the host waits for
 // the one before it, so the GPU never idles as long as the host can enqueue a batch faster than the GPU runs one; every
@@ -1892,6 +1900,8 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         BH_TRY(wait_mirror(c, a.tag, kNever, &mw));          // the final state
         if (!mw.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
         fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
+        fin_out->results_final = (mw.status == BH_CG_SOLVED || mw.status == BH_CG_MAX_ITER_REACHED || mw.status == BH_CG_NONE);
+        fin_out->tag = a.tag;
         return BH_OK;
     }
     // Box constraints with register-resident vectors: no init kernel — the first H*p forms p0 = -mask(g) on the fly and
@@ -1966,20 +1976,29 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     BH_TRY(wait_mirror(c, a.tag, launched, &mw));      // the final state (all enqueued iterations have run or were no-ops)
     if (!mw.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
     fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
+    fin_out->tag = a.tag;
     return BH_OK;
 }
 
-// After the caller's hipStreamSynchronize: bookkeeping of one finished projected_cg.
-static int32_t pcg_finish(bh_hess* H, const PcgFin& fin) {
+// The tie log the final publish_state left next to the progress word.  The words are stored before the progress word by the
+// same thread, but only a drained stream makes that an ordering guarantee.
+static void read_tie_words(bh_hess* H) {
+    const unsigned long long tw = g_ctx.cg.h_mirror[1], mb = g_ctx.cg.h_mirror[2];
+    H->margin_kind = (int)((tw >> 48) & 0xf); H->tie_flags = (int)((tw >> 40) & 0xff);
+    H->tie_first = (int)((tw >> 20) & 0xfffff); H->margin_at = (int)(tw & 0xfffff);
+    memcpy(&H->min_margin, &mb, sizeof(double));
+    H->tie_read = true;
+}
+
+// Bookkeeping of one finished projected_cg (normally after the caller's hipStreamSynchronize; `drained` = false when the
+// device-pointer entry point returned on results_final without draining).
+static int32_t pcg_finish(bh_hess* H, const PcgFin& fin, bool drained = true) {
     if (!fin.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
     H->stats.n_pcg += 1;
     H->last_n_hmul = fin.n_hmul;
-    {   // the tie log the final publish_state left next to the progress word (the stream has been drained)
-        const unsigned long long tw = g_ctx.cg.h_mirror[1], mb = g_ctx.cg.h_mirror[2];
-        H->margin_kind = (int)((tw >> 48) & 0xf); H->tie_flags = (int)((tw >> 40) & 0xff);
-        H->tie_first = (int)((tw >> 20) & 0xfffff); H->margin_at = (int)(tw & 0xfffff);
-        memcpy(&H->min_margin, &mb, sizeof(double));
-    }
+    H->tie_tag = fin.tag;
+    H->tie_read = false;
+    if (drained) read_tie_words(H);     // else: read on demand (bh_pcg_tie_info drains first)
     H->stats.n_hmul += fin.n_hmul;
     H->stats.n_cg_iter += fin.iter - 1;
     H->stats.n_proj += fin.iter;
@@ -2031,10 +2050,13 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
     if (trace_cap > 0) count_d2h((size_t)4 * trace_cap * sizeof(double));
     if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
-    // EXPERIMENT (BH_SKIP_FINAL_SYNC=1; A/B only): how much of a subproblem is the final hipStreamSynchronize?
-    static const bool skip_sync = getenv("BH_SKIP_FINAL_SYNC") != nullptr && atoi(getenv("BH_SKIP_FINAL_SYNC")) != 0;
-    if (!(skip_sync && in_place && trace_cap == 0)) BH_TRY(sync_flush());      // drains the over-launched no-op kernels; orders w for any consumer
-    BH_TRY(pcg_finish(H, fin));
+    // The final hipStreamSynchronize costs ~10 us (measured: 650 -> 640 us per config-3 subproblem).  It is skipped when nothing
+    // can still be written: device vectors used in place (no staged result to fetch), no trace, and the loop stopped in the
+    // prologue of an H*p launch (PcgFin::results_final) — w was complete before that launch began.  Otherwise the stream is
+    // drained as before (option "final_sync" = 1 forces it).
+    const bool drain = g_ctx.opt_final_sync || !(in_place && trace_cap == 0 && fin.results_final);
+    if (drain) BH_TRY(sync_flush());      // drains the over-launched no-op kernels; orders w for any consumer
+    BH_TRY(pcg_finish(H, fin, drain));
     if (status) *status = fin.status;
     if (iters) *iters = fin.iter;
     if (n_hmul_out) *n_hmul_out = fin.n_hmul;
@@ -2050,6 +2072,14 @@ int32_t bh_pcg(bh_hess* H, bh_proj* P, const double* g_minor, const double* w_l,
 int32_t bh_pcg_tie_info(const bh_hess* H, int32_t* tie_flags, int32_t* first_tie_hmul, double* min_margin, int32_t* min_margin_kind,
                         int32_t* min_margin_hmul) {
     if (!H) return fail(BH_ERR_INVALID_ARG, "NULL bh_hess");
+    if (!H->tie_read) {
+        // the call returned without draining the stream: do it now, and make sure no later call has overwritten the words
+        bh_hess* Hm = const_cast<bh_hess*>(H);
+        if (g_ctx.init && g_ctx.stream) BH_HIP(hipStreamSynchronize(g_ctx.stream));
+        if ((unsigned)((g_ctx.cg.h_mirror[0] >> 48) & 0xffffu) != (H->tie_tag & 0xffffu))
+            return fail(BH_ERR_PRECONDITION, "bh_pcg_tie_info: another projected_cg has run since this handle's last one (ask right after the call)");
+        read_tie_words(Hm);
+    }
     if (tie_flags) *tie_flags = H->tie_flags;
     if (first_tie_hmul) *first_tie_hmul = H->tie_first;
     if (min_margin) *min_margin = H->min_margin;

@@ -579,10 +579,14 @@ class DeviceVector:
             pass
 
 
+_PCG_OUT = (ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0))       # reused output cells: one ctypes allocation less per call
+_PCG_REF = tuple(ct.byref(x) for x in _PCG_OUT)
+
+
 def projected_cg_dev(g_dev, H, wl_dev, wu_dev, lincons, kappa2, w_out_dev, atol=SQRT_EPS, atol_f2b=1e-10):
     """``bh_pcg_dev``: all vectors already in HBM (what bench.py times).  Returns (status, iters, n_hmul)."""
-    status, iters, n_hmul = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0)
-    check(_lib.lib().bh_pcg_dev(H.handle, lincons.handle, g_dev.ptr, wl_dev.ptr, wu_dev.ptr, float(kappa2), float(atol),
-                                float(atol_f2b), w_out_dev.ptr, ct.byref(status), ct.byref(iters), None, 0, ct.byref(n_hmul)),
-          "bh_pcg_dev")
-    return CGStatus(status.value), iters.value, n_hmul.value
+    rc = _lib.lib().bh_pcg_dev(H._h, lincons.handle, g_dev._p, wl_dev._p, wu_dev._p, kappa2, atol, atol_f2b, w_out_dev._p,
+                               _PCG_REF[0], _PCG_REF[1], None, 0, _PCG_REF[2])
+    if rc != 0:
+        check(rc, "bh_pcg_dev")
+    return CGStatus(_PCG_OUT[0].value), _PCG_OUT[1].value, _PCG_OUT[2].value

@@ -291,6 +291,11 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
  *   "cg_fused"       [1] box constraints on one rank: two kernels per CG iteration (the H*p launch forms p and takes the exit test,
  *                        one kernel reduces the slabs and updates w, r, v) instead of three (H*p, slab reduction, step kernel)
+ *   "final_sync"     [0] bh_pcg_dev: 1 = always drain the stream before returning.  0 = return as soon as the results are final:
+ *                        when the caller's device vectors are used in place and the loop was stopped by its exit test (solved /
+ *                        iterations exhausted), w was complete before the launch that reported the stop began, and only
+ *                        prologue-only launches that write nothing are still in flight (saves ~10 us per call); every other case
+ *                        drains as before.
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2), faster, errors accumulate)
