@@ -348,6 +348,38 @@ def test_pcg_random_instances(bh, cg_fused, d, n, q, mA, nfix, seed):
     H.close()
 
 
+@pytest.mark.parametrize("d,n,nfix,kappa2", [(60, 5000, 300, 0.1), (40, 8192, 0, 0.1), (50, 9001, 700, 0.1), (30, 16384, 1000, 0.3),
+                                             (33, 16385, 5, 0.3), (2000, 2048, 100, 0.01), (700, 1000, 7, 0.01)])
+def test_pcg_wide_rows_every_kernel_geometry(bh, cg_fused, d, n, nfix, kappa2):
+    """projected_cg with box constraints through every geometry of the row-streaming kernel that carries the CG prologue —
+    <256,2,8> … <512,8,2>, the <512,16,1> variant that parks the vector in LDS (8192 < n <= 16384) — and through the column-panel
+    fallback above it (n = 16385), on both iteration shapes, against the oracle (few rows: rank-deficient H, so the loop also meets
+    near-zero curvature directions)."""
+    rng = np.random.default_rng(n + d)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, nfix, replace=False)] = True
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix if nfix else None, l=-np.ones(n), u=np.ones(n))
+    g = J.T @ rng.standard_normal(d) + 1e-3 * rng.standard_normal(n)
+    w_l, w_u = R.build_step_bounds(np.where(fix, 1.0, 0.0), cons_o, 0.5 * np.linalg.norm(g))
+    Ho = R.AlHessian(J, np.zeros((0, n)), 2.0)
+    tr = R.CGTrace()
+    w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, kappa2, trace=tr)
+    H = bh.AlHessian(J, None, 2.0)
+    cons = bh.MixedConstraints(A, None, fix)
+    w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, kappa2, trace_cap=32, full_output=True)
+    assert int(status) == int(s_ref) and info["iters"] == it_ref and info["n_hmul"] == tr.n_hmul, (status, info["iters"], s_ref, it_ref)
+    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, kappa2, w_ref), relnorm(w, w_ref)
+    k = min(len(tr.rows), 32)
+    ref_rows = np.array(tr.rows[:k])
+    m = np.isfinite(ref_rows)
+    np.testing.assert_allclose(info["trace"][:k][m], ref_rows[m], rtol=1e-6, atol=1e-12)
+    w2, status2, info2 = bh.projected_cg(g, H, w_l, w_u, cons, kappa2, full_output=True)      # second call: launch schedule from the hint
+    assert np.array_equal(w, w2) and int(status2) == int(status) and info2["iters"] == info["iters"]
+    H.close()
+
+
 def test_pcg_config5_shape_linear_constraints(bh, proj_form):
     """BASELINE config 5 shape at oracle-sized d: n=1024, mA=16 linear equalities + p=128 active bounds (mpp=144)."""
     d, n, mA = 2048, 1024, 16
