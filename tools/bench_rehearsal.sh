@@ -1,16 +1,27 @@
 #!/bin/bash
-# GPU box (one GPU): rehearse bench.py's N > 1 flow — all ranks on device 0, gloo for torch, the library's all-reduce over its
-# peer-buffer transport (hipIpc between processes on one device).  Exercises the script's multi-rank flow; not a measurement.
+# GPU box (one GPU): rehearse bench.py's N > 1 flow — all ranks on device 0, gloo for torch.  Not a measurement.
+#   1. N = 2 weak and N = 3 strong scaling over the library's peer-buffer transport (hipIpc between processes on one device);
+#   2. N = 2 with BH_COMM=both — the configuration bench.py picks on a real multi-GPU node: the RCCL call site is bound to the
+#      host-staged stand-in (RCCL itself refuses duplicate devices), the peer-buffer transport comes up next to it, the headline
+#      is timed on the "RCCL" path and the comm section switches paths, times both all-reduces and re-runs on the peer path.
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out
-export BH_BENCH_REHEARSAL=1 BH_COMM=ipc
+export BH_BENCH_REHEARSAL=1
 rc=0
-for cfg in "2 weak" "3 strong"; do
+for cfg in "2 weak ipc" "3 strong ipc" "2 weak both"; do
     set -- $cfg
+    export BH_COMM=$3
+    if [ "$3" = "both" ]; then
+        g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/multirank/staged_rccl.cpp \
+            -o tests/multirank/libstaged_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
+        export BH_RCCL_LIB=$R/tests/multirank/libstaged_rccl.so BH_STAGED_RCCL_SHM=/bh_rehearsal_$$
+    fi
     timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port 2953$1 \
-        bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2.log 2>&1 || rc=$?
-    tail -1 gpurun_out/bench_rehearsal_$1_$2.log | cut -c1-1800
-    [ $rc -eq 0 ] || { tail -30 gpurun_out/bench_rehearsal_$1_$2.log; exit $rc; }
+        bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2_$3.log 2>&1 || rc=$?
+    rm -f /dev/shm/bh_rehearsal_$$
+    tail -1 gpurun_out/bench_rehearsal_$1_$2_$3.log | cut -c1-1200
+    grep -o '"comm": {[^}]*}[^}]*}' gpurun_out/bench_rehearsal_$1_$2_$3.log | cut -c1-900
+    [ $rc -eq 0 ] || { tail -30 gpurun_out/bench_rehearsal_$1_$2_$3.log; exit $rc; }
 done
 exit $rc
