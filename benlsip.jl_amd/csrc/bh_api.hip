@@ -375,6 +375,7 @@ struct bh_proj {
     double* M = nullptr;           // mA x mA: A_free A_free' (lower triangle), kept for rank-one downdates (bh_cauchy_step)
     double* Lr = nullptr;          // mA x mA + mA: chol(M) and its reciprocal diagonal (reduced form)
     int* info = nullptr;           // device flag of chol_lower_kernel
+    double* tpart = nullptr;       // (ldA/32 + 1) x mA: per-workgroup partials of A_free r (four-kernel CG iteration)
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
     bool M_valid = false;          // M = A_free A_free' for the CURRENT active set (false after factor-only downdates)
     std::vector<uint64_t> last_chunks;   // fixvars of the last successful bh_proj_set_active (reduced form: skip identical pushes)
@@ -889,6 +890,7 @@ int32_t ensure_reduced_buffers(bh_proj* P) {
     if (!P->M) BH_TRY(dev_alloc(&P->M, mA * mA));
     if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, mA * mA + mA));
     if (!P->info) BH_TRY(dev_alloc(&P->info, 1));
+    if (!P->tpart) BH_TRY(dev_alloc(&P->tpart, (P->ldA / 32 + 1) * std::max<int64_t>(mA, 1)));
     return BH_OK;
 }
 
@@ -1724,7 +1726,7 @@ int32_t bh_proj_destroy(bh_proj* P) {
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
     dev_free(P->Lr); dev_free(P->M); dev_free(P->info);
-    dev_free(P->newidx); dev_free(P->counts); dev_free(P->chunks_dev);
+    dev_free(P->newidx); dev_free(P->counts); dev_free(P->chunks_dev); dev_free(P->tpart);
     delete P;
     return BH_OK;
 }
@@ -1831,23 +1833,37 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // H*p launch forms p on the fly and takes the exit test, one 128-workgroup kernel reduces the slabs and updates w, r, v.
     // (g doubles as the first H*p input, so it must be readable up to the padded length: workspace copy or n == ld.)
     const int rs_cfg = multi_panel(H) ? -1 : pick_config(H->nchunks);
-    if (box && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && !comm_active() && max_iter >= 1 && (gp == c.g || n == n_pad)) {
+    // General constraints in the reduced projection form with mA <= 64 get the same treatment in FOUR kernels instead of seven:
+    // H*p (p formed on the fly), reduce/update leaving partials of A_free r, the small triangular solve (summing those partials),
+    // and left_mul_tr forming v = P(r) with its partials of r.v.
+    const bool fuse_gen = !box && P->reduced && P->mA <= 64 && P->tpart != nullptr;
+    if ((box || fuse_gen) && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && !comm_active() && max_iter >= 1 &&
+        (gp == c.g || n == n_pad)) {
         BH_TRY(hess_ready(H));
         if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
+        if (fuse_gen) {
+            // :702-718 by the init kernels: r = g, w = 0, v = P(r), rtv, p_1 = -v (in c.p), tol_cg, CgState (stop_at = 0)
+            hipLaunchKernelGGL((cg_init_kernel<false>), dim3(1), dim3(CG_T), 0, s, a);
+            BH_TRY(launch_project(P, c.r, c.v, c.d_state));
+            hipLaunchKernelGGL(cg_init_finish_kernel, dim3(1), dim3(CG_T), 0, s, a);
+        }
         const int64_t nrows = H->d + H->q_eff;
         const int grid = grid_for(rs_cfg, nrows);
         const int nblk = (H->nchunks + 15) / 16;
         double* pbuf[2] = {c.p, c.p2};
         double* rvbuf[2] = {c.rvpart, c.rvpart + n_pad / 2};
+        const int nch_v = ((int)n + 1) / 2;
+        const int nrv = fuse_gen ? (nch_v + 63) / 64 : nblk;            // who writes the r.v partials: left_mul_tr (64 chunks per workgroup) or the update kernel
         int expect_stop_at = H->last_n_hmul > 0 ? H->last_n_hmul + 1 : 0;     // the launch expected to find the loop finished
         auto launch_stream = [&](int j) -> int32_t {            // H*p of iteration j (1-based), p_j formed on the fly
             RowStreamArgs ra = rs_args(H, nrows, nullptr);
             ra.partials = H->partials;
-            ra.v = gp; ra.negate = 1; ra.negmask = a.fixrank;                       // used by j == 1 only: p_1 = -mask(g)
+            if (fuse_gen) { ra.v = c.p; ra.negate = 0; }                            // used by j == 1 only: p_1 = -P(g), formed by the init kernels
+            else { ra.v = gp; ra.negate = 1; ra.negmask = a.fixrank; }             //                      p_1 = -mask(g), formed on the fly
             CgFuse& f = ra.cf;
-            f.st = c.d_state; f.j = j; f.n = (int)n; f.max_iter = max_iter;
+            f.st = c.d_state; f.j = j; f.n = (int)n; f.max_iter = max_iter; f.init_done = fuse_gen ? 1 : 0;
             f.vvec = c.v; f.p_old = pbuf[(j - 1) & 1]; f.p_new = pbuf[j & 1];
-            f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nblk;
+            f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nrv;
             f.w = wp; f.wl = wlp; f.wu = wup;
             f.sqpart = H->sq_partials; f.gpart = c.gpart;
             f.kappa2 = kappa2; f.atol_f2b = atol_f2b;
@@ -1861,10 +1877,20 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         auto launch_update = [&](int j) {
             CgUpdArgs u{};
             u.st = c.d_state; u.j = j; u.partials = H->partials; u.ld = H->ld; u.nchunks = H->nchunks; u.G = grid;
-            u.sqpart = H->sq_partials; u.gpart = c.gpart; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nblk;
+            u.sqpart = H->sq_partials; u.gpart = c.gpart; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nrv;
             u.p = pbuf[j & 1]; u.w = wp; u.hw = hw; u.r = c.r; u.g = gp; u.v = c.v; u.fixrank = a.fixrank;
             u.n = (int)n; u.atol_neg = atol_negcurv; u.trace = a.trace; u.trace_cap = a.trace_cap; u.mirror = a.mirror; u.tag = a.tag;
-            hipLaunchKernelGGL(cg_reduce_update_kernel, dim3(nblk), dim3(256), 0, s, u);
+            if (!fuse_gen) {
+                hipLaunchKernelGGL((cg_reduce_update_kernel<false>), dim3(nblk), dim3(256), 0, s, u);
+                return;
+            }
+            u.A = P->Ad; u.ldA = P->ldA; u.mA = (int)P->mA; u.tpart = P->tpart; u.init_in_memory = 1;
+            hipLaunchKernelGGL((cg_reduce_update_kernel<true>), dim3(nblk), dim3(256), 0, s, u);
+            // y = (A_free A_free')^{-1} (A_free r): partial sums + the two triangular solves; then v = r_free - A_free'y and r.v
+            ProjArgs pa = proj_args(P, c.d_state, true);
+            pa.tpart = P->tpart; pa.tpart_nblk = nblk; pa.rvpart = rvbuf[j & 1]; pa.fused_j = j;
+            hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
+            hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 4>), dim3((nch_v + 63) / 64), dim3(256), 0, s, pa, (const double*)c.r, c.v);
         };
         // Launch order: S(1) | U(1) S(2) | U(2) S(3) | ...: the stream kernel of iteration j+1 is what detects "solved" after
         // iteration j, so it is always enqueued together with U(j) (as a gated no-op if the loop ended in U(j)).

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(CG_T) void cg_init_finish_kernel(CgArgs a) {
         st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
         st->iter = 1; st->max_iter = a.max_iter;
         st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
-        st->n_hmul = 0; st->need_proj = 0;
+        st->n_hmul = 0; st->need_proj = 0; st->stop_at = 0;
         tie_reset(st);
         st->done = (1 <= a.max_iter) ? 0 : 1;
         st->status = cg_final_status(st);

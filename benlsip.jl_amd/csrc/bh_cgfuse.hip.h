@@ -40,14 +40,21 @@ struct CgUpdArgs {
     double atol_neg;
     double* trace; int trace_cap;
     unsigned long long* mirror; unsigned tag;
+    // GEN (linear equalities, reduced projection form): no v / r.v here — this kernel leaves the per-workgroup partials of
+    // A_free r, trsv_small_kernel sums and solves, proj_left_mul_tr_kernel forms v = P(r) and the partials of r.v
+    const double* A; int64_t ldA; int mA;
+    double* tpart;                  // [gridDim.x][mA]
+    int init_in_memory;             // j == 1: r = g and w = 0 are already in memory (init kernels), not taken from g
 };
 
 // grid = ceil(nchunks / 16) workgroups of 256 threads = 16 chunks x 16 slab lanes (as reduce_partials_kernel).
+template <bool GEN>
 __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
     CgState* st = a.st;
     if (st->stop_at != 0 && a.j > st->stop_at) return;
     __shared__ double2 sm[16][17];
     __shared__ double rvs[16];
+    __shared__ double2 rsm[16];                  // GEN: the masked new r of this workgroup's 16 chunks
     const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool valid = c < a.nchunks;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
         const bool e0 = 2 * c < a.n, e1 = 2 * c + 1 < a.n;
         const double2 pk = reinterpret_cast<const double2*>(a.p)[c];
         double2 wk = make_double2(0.0, 0.0), hwk = make_double2(0.0, 0.0), rk;
-        if (a.j == 1) {
+        if (a.j == 1 && !a.init_in_memory) {
             rk = reinterpret_cast<const double2*>(a.g)[c];           // r = g_minor (:705), w = 0 (:702)
         } else {
             rk = reinterpret_cast<const double2*>(a.r)[c];
@@ -130,23 +137,47 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
         }
         if (!e0) { wk.x = 0.0; hwk.x = 0.0; rk.x = 0.0; vk.x = 0.0; }
         if (!e1) { wk.y = 0.0; hwk.y = 0.0; rk.y = 0.0; vk.y = 0.0; }
-        if (cont) rv_part = fma(rk.y, vk.y, rk.x * vk.x);            // :743 (this chunk)
+        if (cont && !GEN) rv_part = fma(rk.y, vk.y, rk.x * vk.x);    // :743 (this chunk)
         if (add_w || a.j == 1) {
             reinterpret_cast<double2*>(a.w)[c] = wk;
             if (a.hw != nullptr) reinterpret_cast<double2*>(a.hw)[c] = hwk;
         }
         if (cont || a.j == 1) {
             reinterpret_cast<double2*>(a.r)[c] = rk;
-            reinterpret_cast<double2*>(a.v)[c] = vk;
+            if (!GEN) reinterpret_cast<double2*>(a.v)[c] = vk;
         }
+        if (GEN) rsm[cl] = vk;                                       // mask(r_new): what A_free multiplies
+    } else if (GEN && rl == 0) {
+        rsm[cl] = make_double2(0.0, 0.0);
     }
-    if (rl == 0) rvs[cl] = rv_part;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
+    if (!GEN) {
+        if (rl == 0) rvs[cl] = rv_part;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += rvs[q];
-        a.rvpart_out[blockIdx.x] = t;
+            for (int q = 0; q < 16; ++q) t += rvs[q];
+            a.rvpart_out[blockIdx.x] = t;
+        }
+    } else {
+        // left_mul, reduced form (src/polyhedral_constraints.jl:86-98 with the fixed components masked out): this workgroup's
+        // share of A_free r for every row of A — thread (rl, cl) takes rows rl, rl+16, ... and chunk cl; the 16 chunk-lanes of a
+        // row are one DPP row
+        __syncthreads();
+        if (cont) {
+            const double2 rm = rsm[cl];
+            const int64_t ldA2 = a.ldA >> 1;
+            const double2* A2 = reinterpret_cast<const double2*>(a.A);
+            for (int i = rl; i < a.mA; i += 16) {
+                double prod = 0.0;
+                if (valid) {
+                    const double2 av = A2[(int64_t)i * ldA2 + c];
+                    prod = fma(av.y, rm.y, av.x * rm.x);
+                }
+                prod = row16_sum(prod);
+                if (cl == 0) a.tpart[(int64_t)blockIdx.x * a.mA + i] = prod;
+            }
+        }
     }
 
     // ---- workgroup 0 commits the iteration ----------------------------------------------------------------------------------

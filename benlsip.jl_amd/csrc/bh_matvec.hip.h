@@ -22,6 +22,7 @@ enum { MODE_JV = 0, MODE_JTV = 1, MODE_FUSED = 2 };
 struct CgFuse {
     CgState* st;
     int j;                  // iteration of this launch, 1-based (the reference's `iter` while the H*p of :722 runs)
+    int init_done;          // general constraints: :702-718 was done by the init kernels (p_1 = -P(g) is in memory, CgState is set)
     int n, max_iter;
     const double* vvec;     // v = P(r) after iteration j-1                (j >= 2)
     const double* p_old;    // p_{j-1}                                     (j >= 2)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
         if (f.j == 1) {
             // projected_cg's initialisation (:702-718) belongs to workgroup 0: r = g, v = P(r) = mask(g), p = -v (formed above),
             // rtv = r.v, tol_cg = kappa2*||v||, iter = 1, all flags down
-            if (blockIdx.x == 0) {
+            if (blockIdx.x == 0 && !f.init_done) {
                 double rtv0 = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {        // vv = -mask(g):  r.v = v.v = sum of squares of the free components

@@ -21,9 +21,18 @@ struct ProjArgs {
     double* tw;             // mpp workspace
     const CgState* state;   // NULL, or skip unless (!done && need_proj)
     int reduced;            // 1: reduced form  v_free = r_free - A_free'(A_free A_free')^{-1} A_free r_free, v_fix = 0
+    // four-kernel general-constraint CG iteration (bh_cgfuse.hip.h):
+    const double* tpart;    // trsv_small_kernel: tw[i] = sum over tpart_nblk workgroups of tpart[b*mA + i] (A_free r partials) first
+    int tpart_nblk;
+    double* rvpart;         // proj_left_mul_tr_kernel: this workgroup's partial of r.v
+    int fused_j;            // > 0: launch of iteration fused_j — skipped iff the loop stopped at or before it (CgState::stop_at)
 };
 
 __device__ __forceinline__ bool proj_skip(const CgState* st) { return st != nullptr && (st->done || !st->need_proj); }
+__device__ __forceinline__ bool proj_skip(const ProjArgs& a) {
+    if (a.fused_j > 0) return a.state->stop_at != 0 && a.fused_j >= a.state->stop_at;
+    return proj_skip(a.state);
+}
 
 // Box-only projection: v = fixed ? 0 : r.
 __global__ __launch_bounds__(256) void proj_mask_kernel(const double* __restrict__ r, double* __restrict__ v, const int* fixrank, int n,
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const do
 // thread serialise (33.8 us at mA = 512 with RG = 4).
 template <bool SUBTRACT, int RG>
 __global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
-    if (proj_skip(a.state)) return;
+    if (proj_skip(a)) return;
     __shared__ double2 sm[RG][64];
     const int nch = (a.n + 1) >> 1;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -90,7 +99,35 @@ __global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, c
     }
     sm[rg][cl] = acc;
     __syncthreads();
-    if (rg != 0 || c >= nch) return;
+    if (rg != 0) return;
+    if (SUBTRACT && a.rvpart != nullptr && a.reduced) {
+        // four-kernel CG iteration: v = r - A_free'y on the free variables, and this workgroup's share of r.v (:743) — the whole
+        // of wave 0 stays together for the reduction
+        double2 t = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int g4 = 0; g4 < RG; g4 += 4) {
+            const double qx = (sm[g4][cl].x + sm[g4 + 1][cl].x) + (sm[g4 + 2][cl].x + sm[g4 + 3][cl].x);
+            const double qy = (sm[g4][cl].y + sm[g4 + 1][cl].y) + (sm[g4 + 2][cl].y + sm[g4 + 3][cl].y);
+            t.x = (g4 == 0) ? qx : t.x + qx;
+            t.y = (g4 == 0) ? qy : t.y + qy;
+        }
+        double rv = 0.0;
+        if (c < nch) {
+            const int j0 = 2 * c, j1 = 2 * c + 1;
+            int k0 = -1, k1 = -1;
+            if (a.fixrank != nullptr) { k0 = a.fixrank[j0]; if (j1 < a.n) k1 = a.fixrank[j1]; }
+            const double r0 = r[j0], r1 = (j1 < a.n) ? r[j1] : 0.0;
+            const double v0 = (k0 >= 0) ? 0.0 : r0 - t.x;
+            const double v1 = (k1 >= 0 || j1 >= a.n) ? 0.0 : r1 - t.y;
+            out[j0] = v0;
+            if (j1 < a.n) out[j1] = v1;
+            rv = fma(r1, v1, r0 * v0);
+        }
+        rv = wave_sum(rv);
+        if (cl == 0) a.rvpart[blockIdx.x] = rv;
+        return;
+    }
+    if (c >= nch) return;
     acc = make_double2(0.0, 0.0);
 #pragma unroll
     for (int g4 = 0; g4 < RG; g4 += 4) {         // groups of four, each combined as (0+1)+(2+3), then added in order
@@ -500,9 +537,19 @@ __global__ __launch_bounds__(CG_T) void chol_downdate_kernel(double* __restrict_
 // row stride 65: conflict-free both row- and column-wise); wave 0 then runs the 2 x m dependent steps
 // (readlane + LDS read + fma) with the reciprocal diagonal from chol_small_kernel.
 __global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
-    if (proj_skip(a.state)) return;
+    if (proj_skip(a)) return;
     __shared__ double t[64 * 65];
+    __shared__ double tq[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = a.mpp;
+    if (a.tpart != nullptr) {
+        // right-hand side from the per-workgroup partials of A_free r: wave q folds a quarter of the workgroups in order
+        const int per = (a.tpart_nblk + 3) / 4;
+        const int b0 = wave * per, b1 = min(a.tpart_nblk, b0 + per);
+        double acc = 0.0;
+        if (lane < m)
+            for (int b = b0; b < b1; ++b) acc += a.tpart[(int64_t)b * m + lane];
+        tq[wave][lane] = acc;
+    }
     const double* __restrict__ L = a.L;
     double tmp[16];
 #pragma unroll
@@ -515,7 +562,8 @@ __global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
     __syncthreads();
     if (wave != 0) return;
     const double di = (lane < m) ? L[(int64_t)m * m + lane] : 0.0;
-    double xi = (lane < m) ? a.tw[lane] : 0.0;
+    double xi = 0.0;
+    if (lane < m) xi = (a.tpart != nullptr) ? ((tq[0][lane] + tq[1][lane]) + (tq[2][lane] + tq[3][lane])) : a.tw[lane];
 #pragma unroll 8
     for (int j = 0; j < m; ++j) {                           // forward: L y = t
         const double lij = t[lane * 65 + j];

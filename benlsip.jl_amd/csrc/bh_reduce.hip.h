@@ -49,6 +49,14 @@ __device__ __forceinline__ double wave_reduce(double x, Op op) {
     return x;
 }
 __device__ __forceinline__ double wave_sum(double x) { return wave_reduce(x, OpSum()); }
+// Sum over the 16 lanes of one DPP row (lanes 16k .. 16k+15): the first four steps of the butterfly.
+__device__ __forceinline__ double row16_sum(double x) {
+    x = x + dpp_mov_f64<0xB1>(x);
+    x = x + dpp_mov_f64<0x4E>(x);
+    x = x + dpp_mov_f64<0x141>(x);
+    x = x + dpp_mov_f64<0x140>(x);
+    return x;
+}
 __device__ __forceinline__ double wave_min(double x) { return wave_reduce(x, OpMinNan()); }
 
 // Block-wide reduction of NV values at once; fixed combination order -> bit-reproducible.
