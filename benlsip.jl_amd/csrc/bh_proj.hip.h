@@ -546,8 +546,17 @@ __global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
         const int per = (a.tpart_nblk + 3) / 4;
         const int b0 = wave * per, b1 = min(a.tpart_nblk, b0 + per);
         double acc = 0.0;
-        if (lane < m)
-            for (int b = b0; b < b1; ++b) acc += a.tpart[(int64_t)b * m + lane];
+        if (lane < m) {
+            int b = b0;
+            for (; b + 8 <= b1; b += 8) {           // eight loads in flight, then the adds in index order
+                double x[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) x[k] = a.tpart[(int64_t)(b + k) * m + lane];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += x[k];
+            }
+            for (; b < b1; ++b) acc += a.tpart[(int64_t)b * m + lane];
+        }
         tq[wave][lane] = acc;
     }
     const double* __restrict__ L = a.L;
