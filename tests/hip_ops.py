@@ -219,7 +219,7 @@ class ShadowOps:
             # relative accuracy is eps*||g||/||P(-g)||, whoever computes it)
             rng = np.random.default_rng(self.minor)
             sens = 0.0
-            for _ in range(3):
+            for _ in range(16):         # (the outcome can be bimodal — e.g. 37 or 41 breakpoints — so a handful of samples is not enough)
                 sh2 = copy.copy(lincons)
                 sh2._dev = None
                 sh2.fixvars = fix0.copy()

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("row_stream_kernel", "reduce_partials_kernel", "cg_step_reg_kernel", "cg_step_kernel", "cg_init", "proj_", "trsv", "chol",
+    for key in ("row_stream_kernel", "reduce_partials_kernel", "cg_reduce_update_kernel", "reduce_exchange_kernel", "cg_step_reg_kernel", "cg_step_kernel", "cg_init", "proj_", "trsv", "chol",
                 "gram", "linesearch", "step_bounds", "cauchy", "synth_fill", "reduce_scalar", "weighted_sqsum"):
         if key in name:
             if key == "row_stream_kernel":
