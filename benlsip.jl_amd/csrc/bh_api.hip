@@ -1080,7 +1080,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(0, atoll(s));
     if (const char* s = getenv("BH_PINGPONG")) g_ctx.opt_pingpong = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_PROJ_FORM")) g_ctx.opt_proj_form = atoll(s) ? 1 : 0;
-    if (const char* s = getenv("BH_CG_FUSED")) g_ctx.opt_cg_fused = atoll(s) ? 1 : 0;
+    if (const char* s = getenv("BH_CG_FUSED")) g_ctx.opt_cg_fused = std::min<int64_t>(std::max<int64_t>(0, atoll(s)), 2);
     if (const char* s = getenv("BH_FINAL_SYNC")) g_ctx.opt_final_sync = atoll(s) ? 1 : 0;
     g_ctx.init = true;
     return BH_OK;
@@ -1146,7 +1146,11 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "pingpong")) { g_ctx.opt_pingpong = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "proj_form")) { g_ctx.opt_proj_form = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "fold_init")) { g_ctx.opt_fold_init = value ? 1 : 0; return BH_OK; }
-    if (!strcmp(key, "cg_fused")) { g_ctx.opt_cg_fused = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cg_fused")) {
+        if (value < 0 || value > 2) return fail(BH_ERR_INVALID_ARG, "cg_fused is 0, 1 (box constraints) or 2 (also linear equalities)");
+        g_ctx.opt_cg_fused = value;
+        return BH_OK;
+    }
     if (!strcmp(key, "final_sync")) { g_ctx.opt_final_sync = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
@@ -1836,7 +1840,9 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // General constraints in the reduced projection form with mA <= 64 get the same treatment in FOUR kernels instead of seven:
     // H*p (p formed on the fly), reduce/update leaving partials of A_free r, the small triangular solve (summing those partials),
     // and left_mul_tr forming v = P(r) with its partials of r.v.
-    const bool fuse_gen = !box && P->reduced && P->mA <= 64 && P->tpart != nullptr;
+    // (opt-in, cg_fused = 2: measured at config 5 it buys 0-2 % — the 64-step triangular solve and the single-workgroup kernels
+    // around it stay latency-bound — and it changes pHp's rounding like the box form does)
+    const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 2 && P->reduced && P->mA <= 64 && P->tpart != nullptr;
     if ((box || fuse_gen) && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && !comm_active() && max_iter >= 1 &&
         (gp == c.g || n == n_pad)) {
         BH_TRY(hess_ready(H));

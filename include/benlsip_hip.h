@@ -290,7 +290,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "pcg_batch"      [0] CG iterations enqueued per launch-ahead batch; 0 = by problem size (1 when an H*p streams >= 100 us)
  *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
  *   "cg_fused"       [1] box constraints on one rank: two kernels per CG iteration (the H*p launch forms p and takes the exit test,
- *                        one kernel reduces the slabs and updates w, r, v) instead of three (H*p, slab reduction, step kernel)
+ *                        one kernel reduces the slabs and updates w, r, v) instead of three (H*p, slab reduction, step kernel);
+ *                        2: also linear equalities (reduced form, mA <= 64): four kernels instead of seven; 0: the round-1 shapes
  *   "final_sync"     [0] bh_pcg_dev: 1 = always drain the stream before returning.  0 = return as soon as the results are final:
  *                        when the caller's device vectors are used in place and the loop was stopped by its exit test (solved /
  *                        iterations exhausted), w was complete before the launch that reported the stop began, and only
