@@ -82,10 +82,19 @@ def pmc_traffic():
 
 
 def run_steps(bh, H, cons, dv, kappa2, steps):
-    out = None
+    """`steps` back-to-back bh_pcg_dev calls (each one a complete, synchronous subproblem).  The argument objects are built once:
+    what is timed is the library call, not Python's marshalling of fourteen arguments."""
+    import ctypes as ct
+    lib = bh._lib.lib()
+    status, iters, n_hmul = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0)
+    args = (H.handle, cons.handle, dv["g"].ptr, dv["wl"].ptr, dv["wu"].ptr, ct.c_double(kappa2), ct.c_double(bh.operators.SQRT_EPS),
+            ct.c_double(1e-10), dv["w"].ptr, ct.byref(status), ct.byref(iters), None, ct.c_int64(0), ct.byref(n_hmul))
+    fn = lib.bh_pcg_dev
     for _ in range(steps):
-        out = bh.projected_cg_dev(dv["g"], H, dv["wl"], dv["wu"], cons, kappa2, dv["w"])
-    return out
+        rc = fn(*args)
+        if rc != 0:
+            bh._lib.check(rc, "bh_pcg_dev")
+    return bh.CGStatus(status.value), iters.value, n_hmul.value
 
 
 def host_synthetic_J(R, d, n, kind, chunk=8192):

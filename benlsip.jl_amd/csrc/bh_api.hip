@@ -1876,7 +1876,9 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
             int slot = -1;
             BH_TRY(profile_begin(H, j - 1, &slot));
-            launch_row_stream_cgp(rs_cfg, ra, grid, s, j == expect_stop_at || j > max_iter);
+            // a handle without history cannot predict its exit: its look-ahead launches (j > 1) take the no-prefetch symbol too, so
+            // that launches which stop in their prologue never show up under the streaming kernel's name in a profile
+            launch_row_stream_cgp(rs_cfg, ra, grid, s, j == expect_stop_at || j > max_iter || (expect_stop_at == 0 && j > 1));
             if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], s));
             return BH_OK;
         };
