@@ -65,3 +65,13 @@ def first_decision_difference(log_a, log_b, eta1=0.25, eta2=0.75):
                 why.append(("pix vs omega (:372)", a[2], b[2], max(abs(a[2] - 1.0), abs(b[2] - 1.0))))
         return k, a, b, why
     return None
+
+
+def assert_rounding_dominated(diff):
+    """The first differing decision of two driver logs must be one the reference's own arithmetic cannot decide: a
+    trust-region ratio whose numerator ared = mx_next - mx is worth no more than a few hundred ulps of mx."""
+    k, a, b, why = diff
+    assert why, (k, a, b)
+    for name, va, vb, extra in why:
+        assert name.startswith("rho vs"), "driver decision %r differs (oracle %r, device %r) at log entry %d" % (name, va, vb, k)
+        assert extra["ared_in_ulps_of_mx"] <= 512.0, (k, name, extra)

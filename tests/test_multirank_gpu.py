@@ -19,7 +19,7 @@ import uuid
 import numpy as np
 import pytest
 
-from _util import R, first_decision_difference, relnorm
+from _util import R, assert_rounding_dominated, first_decision_difference, relnorm
 
 pytestmark = pytest.mark.gpu
 
@@ -168,16 +168,6 @@ def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name
         assert_rounding_dominated(diff)
     assert np.linalg.norm(xs[0]["x"] - x_ref) <= 1e-4 * np.linalg.norm(x_ref)
     assert np.linalg.norm(P["c"](xs[0]["x"])) < 1e-6 and np.linalg.norm(P["A"] @ xs[0]["x"] - P["b"]) < 1e-10
-
-
-def assert_rounding_dominated(diff):
-    """The first differing decision of two driver logs must be one the reference's own arithmetic cannot decide: a
-    trust-region ratio whose numerator ared = mx_next - mx is worth no more than a few hundred ulps of mx."""
-    k, a, b, why = diff
-    assert why, (k, a, b)
-    for name, va, vb, extra in why:
-        assert name.startswith("rho vs"), "driver decision %r differs (oracle %r, device %r) at log entry %d" % (name, va, vb, k)
-        assert extra["ared_in_ulps_of_mx"] <= 512.0, (k, name, extra)
 
 
 def test_launch_schedule_is_rank_independent_at_a_batch_threshold(tmp_path):

@@ -160,3 +160,40 @@ def test_synthetic_generator_is_deterministic_and_sharded():
     assert np.all(np.abs(J) <= 1 / 4.0) and abs(J.mean()) < 0.1
     u = R.splitmix_uniform(7, np.arange(4))
     assert np.all((u >= -1) & (u < 1)) and len(set(u.tolist())) == 4
+
+
+def test_whole_solve_divergence_is_pinned_to_a_rounding_dominated_rho():
+    """The instruments the GPU tests use to say WHERE two whole solves part (driver decision log, first_decision_difference,
+    assert_rounding_dominated), exercised on the oracle against itself: the same solve with H*v summed in two row blocks takes the
+    same decisions for hundreds of log entries and then parts at a trust-region ratio rho = ared/pred whose numerator is a few
+    ulps of mx (src/basic_tralcnlss.jl:353-354) — the reference's algorithm amplifies rounding there, whoever computes H*v."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _util import assert_rounding_dominated, first_decision_difference
+    from nls_problem import NLSProblem
+    P = NLSProblem(256, 48, 2, seed=1)
+    kw = dict(max_outer_iter=30, max_inner_iter=60)
+
+    class TwoBlocks(R.NumpyOps):
+        def hmul(self, H, v):
+            h = H.J.shape[0] // 2
+            z = H.J[:h].T @ (H.J[:h] @ v)
+            z = z + H.J[h:].T @ (H.J[h:] @ v)
+            return z + H.C.T @ ((H.mu * H.C) @ v)
+
+        def projected_cg(self, g, H, wl, wu, lc, k2):
+            w, s, _ = R.projected_cg(g, H, wl, wu, lc, k2, hmul_fn=self.hmul)
+            return w, s
+
+    logs = []
+    xs = []
+    for ops in (R.NumpyOps(), TwoBlocks()):
+        log = []
+        x, y = R.tralcnllss(P.x0, P.r, P.jac_r, P.c, P.jac_c, P.A, P.b, P.x_l, P.x_u, ops=ops, log=log, **kw)
+        logs.append(log)
+        xs.append(x)
+    diff = first_decision_difference(logs[0], logs[1])
+    assert diff is not None and diff[0] >= 300          # a long common prefix ...
+    assert_rounding_dominated(diff)                     # ... ending at a noise rho
+    assert sum(e[0] == "minor" for e in logs[0]) != sum(e[0] == "minor" for e in logs[1])      # 515 vs 559 minor iterates
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-6 * np.linalg.norm(xs[0])

@@ -494,7 +494,7 @@ def test_sphere_regression_through_c_abi(bh, capsys, ops_cls):
     # asserts it); with the Cauchy search on the device as well it leaves the trajectory at such an iterate and ends in the upper
     # part of that band (3.15e-7): asserted at the band's edge, together with the reason.
     from _util import first_decision_difference
-    from test_multirank_gpu import assert_rounding_dominated
+    from _util import assert_rounding_dominated
     log_ref = []
     R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, max_outer_iter=100, max_inner_iter=250, log=log_ref)
     diff = first_decision_difference(log_ref, log)
@@ -513,7 +513,7 @@ def test_sphere_regression_with_the_fused_general_iteration(bh, capsys):
     ||Jp||^2 + mu ||Cp||^2 instead of dot(p, H*p) — the same number in different last bits — so the run leaves the oracle's
     trajectory at an earlier noise rho and ends in the upper part of the band the oracle itself spans (measured 3.15e-7)."""
     from _util import first_decision_difference
-    from test_multirank_gpu import assert_rounding_dominated
+    from _util import assert_rounding_dominated
     bh.set_option("cg_fused", 2)
     try:
         ops, log, log_ref = HipOps(bh), [], []
@@ -1010,6 +1010,91 @@ def test_inner_step_device_chain_against_oracle(bh, capsys, d, n, mA):
     assert per_iter < 8 * n / 4
 
 
+@pytest.mark.parametrize("d,n,q,mA,nfix,seed", [(60, 24, 1, 0, 5, 1), (200, 65, 0, 3, 9, 2), (900, 512, 2, 8, 60, 3)])
+def test_device_pointer_entry_points_match_the_oracle(bh, d, n, q, mA, nfix, seed):
+    """Every *_dev caller-level entry point on its own (bh_grad_dev, bh_hmul_add_dev, bh_step_accumulate_dev, bh_linesearch_dev,
+    bh_minor_iterate_dev, bh_reduced_gradient_norm_dev, bh_model_reduction_dev, bh_cauchy_step_dev) against the oracle's
+    function it replaces (src/basic_tralcnlss.jl:45, :412, :436-437, :766-791, :649-675, :869-875, :458, :574-639), with the transfer
+    counters checked around each call: no n-vector crosses PCIe."""
+    import ctypes as ct
+    rng = np.random.default_rng(seed)
+    lib = bh._lib.lib()
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, nfix, replace=False)] = True
+    xl, xu = -np.ones(n), np.ones(n)
+    x = np.clip(0.3 * rng.standard_normal(n), -0.9, 0.9)
+    x[fix] = np.where(rng.random(nfix) < 0.5, -1.0, 1.0)
+    cons_o = R.make_mixed_constraints(A, L0, fix, l=xl, u=xu)
+    Ho, H = R.AlHessian(J, C, 4.0), bh.AlHessian(J, C, 4.0)
+    cons = bh.MixedConstraints(A, None, fix, l=xl, u=xu)
+    P = cons.handle
+    rx, ybar = rng.standard_normal(d), rng.standard_normal(q)
+    s0 = 0.01 * rng.standard_normal(n)
+    s0[fix] = 0.0
+    dv = {k: bh.DeviceVector(n, v) for k, v in (("x", x), ("s", s0), ("xl", xl), ("xu", xu))}
+    for k in ("g", "gm", "w", "t"):
+        dv[k] = bh.DeviceVector(n)
+    dr = bh.DeviceVector(d, rx)
+    big = 8 * n            # one n-vector
+
+    def moved(fn):
+        st0 = H.stats()
+        fn()
+        st1 = H.stats()
+        return (st1["h2d_bytes"] - st0["h2d_bytes"]) + (st1["d2h_bytes"] - st0["d2h_bytes"])
+
+    # g = J'r + C'ybar (:45)
+    yb = np.ascontiguousarray(ybar)
+    assert moved(lambda: bh._lib.check(lib.bh_grad_dev(H.handle, dr.ptr, bh._lib.ptr(yb), dv["g"].ptr), "grad")) <= 8 * q + 64
+    g_ref = J.T @ rx + C.T @ ybar
+    g = dv["g"].download()
+    assert np.linalg.norm(g - g_ref) <= TOL1 * np.linalg.norm(np.abs(J).T @ np.abs(rx) + np.abs(C).T @ np.abs(ybar))
+    # g_minor = H*s + g (:412)
+    assert moved(lambda: bh._lib.check(lib.bh_hmul_add_dev(H.handle, dv["s"].ptr, dv["g"].ptr, dv["gm"].ptr), "hmul_add")) < big
+    gm = dv["gm"].download()
+    assert relnorm(gm, R.hmul(Ho, s0) + g) <= 1e-12
+    # reduced-gradient norms (:869-875) and the model value (:458)
+    out = ct.c_double()
+    assert moved(lambda: bh._lib.check(lib.bh_reduced_gradient_norm_dev(P, dv["gm"].ptr, ct.byref(out)), "rgn")) < big
+    assert out.value == pytest.approx(R.norm_reduced_gradient(gm, cons_o), rel=1e-10)
+    assert moved(lambda: bh._lib.check(lib.bh_model_reduction_dev(H.handle, dv["g"].ptr, dv["s"].ptr, ct.byref(out)), "mr")) < big
+    assert out.value == pytest.approx(float(g @ s0) + 0.5 * R.vthv(Ho, s0), rel=1e-10, abs=1e-14)
+    # minor_iterate (:649-675) and linesearch on its unscaled direction (:766-791)
+    delta = 0.3 * np.linalg.norm(g)
+    status, iters, nh, alpha = ct.c_int32(), ct.c_int32(), ct.c_int32(), ct.c_double()
+    assert moved(lambda: bh._lib.check(lib.bh_minor_iterate_dev(H.handle, P, dv["x"].ptr, dv["s"].ptr, dv["gm"].ptr, dv["xl"].ptr, dv["xu"].ptr,
+                                                              delta, 0.1, R.SQRT_EPS, 1e-10, dv["w"].ptr, ct.byref(status), ct.byref(iters),
+                                                              ct.byref(nh), ct.byref(alpha)), "minor_iterate_dev")) < big
+    w_ref, st_ref = R.minor_iterate(x, s0, gm, Ho, cons_o, delta, 0.1)
+    w = dv["w"].download()
+    assert status.value == int(st_ref) and relnorm(w, w_ref) <= 1e-8
+    w_l, w_u = R.build_step_bounds(x + s0, cons_o, delta)
+    w_cg, st_cg, _ = R.projected_cg(gm, Ho, w_l, w_u, cons_o, 0.1)
+    dwl, dwu, dwc = bh.DeviceVector(n, w_l), bh.DeviceVector(n, w_u), bh.DeviceVector(n, w_cg)
+    assert moved(lambda: bh._lib.check(lib.bh_linesearch_dev(H.handle, P, dv["gm"].ptr, dwc.ptr, dwl.ptr, dwu.ptr, ct.byref(out)), "ls")) < big
+    assert out.value == pytest.approx(R.linesearch(gm, Ho, w_cg, w_l, w_u, cons_o.fixvars), rel=1e-10)
+    # s .+= w ; g_minor = H*s + g (:436-437)
+    assert moved(lambda: bh._lib.check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["t"].ptr), "acc")) < big
+    assert np.array_equal(dv["s"].download(), s0 + w)
+    assert relnorm(dv["t"].download(), R.hmul(Ho, s0 + w) + g) <= 1e-12
+    # cauchy_step (:574-639) from x, leaving the active set the reference leaves
+    cau_o = R.make_mixed_constraints(A, L0, l=xl, u=xu)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cau_o, delta, R.NumpyOps())
+    cau = bh.MixedConstraints(A, None, None, l=xl, u=xu)
+    chunks = np.zeros((n + 63) // 64, dtype=np.uint64)
+    nbp = ct.c_int32()
+    assert moved(lambda: bh._lib.check(lib.bh_cauchy_step_dev(H.handle, cau.handle, dv["x"].ptr, dv["g"].ptr, dv["xl"].ptr, dv["xu"].ptr, delta,
+                                                            dv["t"].ptr, bh._lib.ptr(chunks), ct.byref(nbp), ct.byref(nh)), "cauchy_dev")) < big
+    fix_dev = np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert np.array_equal(fix_dev, cau_o.fixvars)
+    assert np.linalg.norm(dv["t"].download() - s_ref) <= 1e-9 * max(np.linalg.norm(s_ref), 1e-300)
+    H.close()
+
+
 @pytest.mark.parametrize("n,mA,seed", [(40, 0, 1), (200, 5, 2), (700, 64, 3), (300, 100, 4)])
 def test_device_side_active_set_update_matches_oracle(bh, n, mA, seed):
     """bh_proj_update_active_dev against the reference's active_bounds + add_active! / active_bounds!
@@ -1154,7 +1239,7 @@ def test_full_solve_medium_nls_through_c_abi(bh, capsys):
     import time
     from _util import first_decision_difference
     from nls_problem import NLSProblem
-    from test_multirank_gpu import assert_rounding_dominated
+    from _util import assert_rounding_dominated
     P = NLSProblem(256, 48, 2, seed=1)
     kw = dict(max_outer_iter=30, max_inner_iter=60)
     t0 = time.perf_counter()
