@@ -1071,9 +1071,10 @@ def test_device_pointer_entry_points_match_the_oracle(bh, d, n, q, mA, nfix, see
                                                               ct.byref(nh), ct.byref(alpha)), "minor_iterate_dev")) < big
     w_ref, st_ref = R.minor_iterate(x, s0, gm, Ho, cons_o, delta, 0.1)
     w = dv["w"].download()
-    assert status.value == int(st_ref) and relnorm(w, w_ref) <= 1e-8
     w_l, w_u = R.build_step_bounds(x + s0, cons_o, delta)
     w_cg, st_cg, _ = R.projected_cg(gm, Ho, w_l, w_u, cons_o, 0.1)
+    # (CG amplifies summation-order noise by ~cond(H): the bar is the oracle's own sensitivity, as for projected_cg itself)
+    assert status.value == int(st_ref) and relnorm(w, w_ref) <= max(1e-8, w_tolerance(gm, Ho, w_l, w_u, cons_o, 0.1, w_cg))
     dwl, dwu, dwc = bh.DeviceVector(n, w_l), bh.DeviceVector(n, w_u), bh.DeviceVector(n, w_cg)
     assert moved(lambda: bh._lib.check(lib.bh_linesearch_dev(H.handle, P, dv["gm"].ptr, dwc.ptr, dwl.ptr, dwu.ptr, ct.byref(out)), "ls")) < big
     assert out.value == pytest.approx(R.linesearch(gm, Ho, w_cg, w_l, w_u, cons_o.fixvars), rel=1e-10)
