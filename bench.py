@@ -223,7 +223,9 @@ def main():
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        if rehearsal:
+        # torch.distributed only carries the rendezvous (unique id), the barriers and a few scalars: BH_BENCH_PG=gloo keeps
+        # torch from creating an RCCL communicator of its own next to the library's (experiment switch)
+        if rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -234,7 +236,7 @@ def main():
     if dist is not None and world > 1:
         # RCCL carries the timed region (BASELINE's north_star names it); the library's one-shot peer-buffer exchange is
         # brought up next to it when possible and measured afterwards, outside the timed region.
-        bcast = bh.torch_broadcast_bytes(None if rehearsal else torch.device("cuda", local_rank))
+        bcast = bh.torch_broadcast_bytes(None if (rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo") else torch.device("cuda", local_rank))
         user_choice = "BH_COMM" in os.environ
         os.environ.setdefault("BH_COMM", "both")
         try:
@@ -247,7 +249,7 @@ def main():
             os.environ["BH_COMM"] = "rccl"
             bh.init_distributed(rank, world, bcast)
     elif dist is not None:
-        bh.init_distributed(rank, world, bh.torch_broadcast_bytes(None if rehearsal else torch.device("cuda", local_rank)))
+        bh.init_distributed(rank, world, bh.torch_broadcast_bytes(None if (rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo") else torch.device("cuda", local_rank)))
     comm_mode = os.environ.get("BH_COMM", "rccl") if world > 1 else None
 
     def barrier():
@@ -257,7 +259,7 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    tdev = "cpu" if rehearsal else "cuda"
+    tdev = "cpu" if (rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo") else "cuda"
 
     def gather(values):
         """Every rank's list of floats, as an (N, len) array on every rank."""
