@@ -67,6 +67,7 @@ constexpr int64_t kPeerCap = 1 << 16;                                   // doubl
 constexpr int kPeerBlkCap = (int)(kPeerCap / (2 * kPeerBlockChunks));   // 2048 flags per (parity, rank)
 constexpr size_t kPeerSlotBytes = (size_t)2 * kMaxPeers * kPeerCap * sizeof(double);
 constexpr size_t kPeerFlagBytes = (size_t)2 * kMaxPeers * kPeerBlkCap * sizeof(unsigned long long);
+constexpr size_t kPeerScalBytes = kPeerFlagBytes;                         // one double per (parity, rank, block): scalars that ride along
 
 // An upload in flight (bh_hess_create_async): a worker thread feeds column chunks of the caller's J through two device
 // staging buffers — copy of chunk k+1 on one stream while chunk k is transposed into the row-major image on another.
@@ -1272,7 +1273,7 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
 
     // one allocation = one handle: [slots | flags | seq, arrive].  Fine-grained (uncached) so that a peer's stores and this
     // rank's polls meet in memory, not in somebody's L2.
-    pc.inbox_bytes = kPeerSlotBytes + kPeerFlagBytes + 256;
+    pc.inbox_bytes = kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes + 256;
     hipError_t e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocFinegrained); }
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&pc.inbox, pc.inbox_bytes); }
@@ -1280,7 +1281,7 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
     if (ok) ok = hipMemset(pc.inbox, 0, pc.inbox_bytes) == hipSuccess;
     char* base = static_cast<char*>(pc.inbox);
     const unsigned long long one = 1ull;
-    if (ok) ok = hipMemcpy(base + kPeerSlotBytes + kPeerFlagBytes, &one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;   // seq = 1
+    if (ok) ok = hipMemcpy(base + kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes, &one, sizeof(one), hipMemcpyHostToDevice) == hipSuccess;   // seq = 1
     if (ok) ok = hipDeviceSynchronize() == hipSuccess;
     if (ok && nranks > 1) ok = hipIpcGetMemHandle(&pc.shm->handle[rank], pc.inbox) == hipSuccess;
     if (!ok) pc.shm->failed = 1;
@@ -1308,9 +1309,10 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
         char* b = static_cast<char*>(pc.peer_base[p]);
         a.slots[p] = reinterpret_cast<double*>(b);
         a.flags[p] = reinterpret_cast<unsigned long long*>(b + kPeerSlotBytes);
+        a.scal[p] = reinterpret_cast<double*>(b + kPeerSlotBytes + kPeerFlagBytes);
     }
-    a.seq = reinterpret_cast<unsigned long long*>(base + kPeerSlotBytes + kPeerFlagBytes);
-    a.arrive = reinterpret_cast<unsigned*>(base + kPeerSlotBytes + kPeerFlagBytes + 64);
+    a.seq = reinterpret_cast<unsigned long long*>(base + kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes);
+    a.arrive = reinterpret_cast<unsigned*>(base + kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes + 64);
     a.err = static_cast<unsigned long long*>(dp);
     a.rank = rank; a.nranks = nranks; a.cap = kPeerCap; a.nblk_cap = kPeerBlkCap;
     const char* ts = getenv("BH_PEER_TIMEOUT_S");
@@ -1843,7 +1845,11 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // (opt-in, cg_fused = 2: measured at config 5 it buys 0-2 % — the 64-step triangular solve and the single-workgroup kernels
     // around it stay latency-bound — and it changes pHp's rounding like the box form does)
     const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 2 && P->reduced && P->mA <= 64 && P->tpart != nullptr;
-    if ((box || fuse_gen) && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && !comm_active() && max_iter >= 1 &&
+    // Several ranks: the two-kernel form carries the exchange inside the update kernel when the peer-buffer transport is the
+    // active one (cg_reduce_update_kernel<false, true>: push the workgroup's 32 columns + its rank's share of pHp, wait, sum in
+    // rank order); an RCCL all-reduce cannot sit inside a kernel, so that path keeps the three-kernel form.
+    const bool peer_fused = comm_active() && use_peer_path() && box && (H->nchunks + 15) / 16 <= kPeerBlkCap;
+    if ((box || fuse_gen) && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && (!comm_active() || peer_fused) && max_iter >= 1 &&
         (gp == c.g || n == n_pad)) {
         BH_TRY(hess_ready(H));
         if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
@@ -1888,12 +1894,17 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             u.sqpart = H->sq_partials; u.gpart = c.gpart; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nrv;
             u.p = pbuf[j & 1]; u.w = wp; u.hw = hw; u.r = c.r; u.g = gp; u.v = c.v; u.fixrank = a.fixrank;
             u.n = (int)n; u.atol_neg = atol_negcurv; u.trace = a.trace; u.trace_cap = a.trace_cap; u.mirror = a.mirror; u.tag = a.tag;
+            if (peer_fused) {
+                hipLaunchKernelGGL((cg_reduce_update_kernel<false, true>), dim3(nblk), dim3(256), 0, s, u, g_ctx.peer.args);
+                H->stats.n_allreduce += 1;
+                return;
+            }
             if (!fuse_gen) {
-                hipLaunchKernelGGL((cg_reduce_update_kernel<false>), dim3(nblk), dim3(256), 0, s, u);
+                hipLaunchKernelGGL((cg_reduce_update_kernel<false, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
                 return;
             }
             u.A = P->Ad; u.ldA = P->ldA; u.mA = (int)P->mA; u.tpart = P->tpart; u.init_in_memory = 1;
-            hipLaunchKernelGGL((cg_reduce_update_kernel<true>), dim3(nblk), dim3(256), 0, s, u);
+            hipLaunchKernelGGL((cg_reduce_update_kernel<true, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
             // y = (A_free A_free')^{-1} (A_free r): partial sums + the two triangular solves; then v = r_free - A_free'y and r.v
             ProjArgs pa = proj_args(P, c.d_state, true);
             pa.tpart = P->tpart; pa.tpart_nblk = nblk; pa.rvpart = rvbuf[j & 1]; pa.fused_j = j;

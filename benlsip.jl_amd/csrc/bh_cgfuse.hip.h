@@ -19,6 +19,7 @@
 #include <stdint.h>
 #include "bh_reduce.hip.h"
 #include "bh_cg.hip.h"
+#include "bh_comm.hip.h"
 
 namespace bh {
 
@@ -48,8 +49,11 @@ struct CgUpdArgs {
 };
 
 // grid = ceil(nchunks / 16) workgroups of 256 threads = 16 chunks x 16 slab lanes (as reduce_partials_kernel).
-template <bool GEN>
-__global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
+// PEER: several ranks over the peer-buffer transport (bh_comm.hip.h) — the workgroup's 32 columns of this rank's slab sum and
+// this rank's share of pHp are pushed into every inbox, and the sums over ranks (rank order: identical bits everywhere) take
+// their place before the update.  The exchange is inside the stop_at gate by construction.
+template <bool GEN, bool PEER>
+__global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, PeerArgs pa) {
     CgState* st = a.st;
     if (st->stop_at != 0 && a.j > st->stop_at) return;
     __shared__ double2 sm[16][17];
@@ -84,7 +88,70 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a) {
     sm[rl][cl] = acc;
 
     // ---- the iteration's scalars, recomputed by every wave from the partials (identical bits everywhere) -----------------
-    const double pHp = wave_fixed_sum(a.sqpart, a.G);                                  // :723
+    double pHp = wave_fixed_sum(a.sqpart, a.G);                                        // :723 (this rank's rows)
+    if (PEER) {
+        __shared__ int s_timeout;
+        __shared__ double2 xs[kMaxPeers][16];
+        __shared__ double ps[kMaxPeers];
+        if (tid == 0) s_timeout = 0;
+        __syncthreads();                                    // sm[][] is complete
+        // this rank's slab sum for the workgroup's 16 chunks
+        if (rl == 0) {
+            double2 t = sm[0][cl];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) { t.x += sm[q][cl].x; t.y += sm[q][cl].y; }
+            sm[15][cl] = t;
+        }
+        __syncthreads();
+        const double2 mine = sm[15][cl];
+        const unsigned long long seq = *pa.seq;
+        const int par = (int)(seq & 1ull);
+        const int64_t slot = ((int64_t)par * kMaxPeers + pa.rank) * pa.cap;
+        const int64_t fidx = ((int64_t)par * kMaxPeers + pa.rank) * pa.nblk_cap + blockIdx.x;
+        // push (write-through), drain, meet, raise the flags — as reduce_exchange_kernel
+        if (rl < pa.nranks && valid) sys_store_f64x2(pa.slots[rl] + slot + 2 * (int64_t)c, mine);
+        if (rl < pa.nranks && cl == 0) __hip_atomic_store(pa.scal[rl] + fidx, pHp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (rl < pa.nranks && cl == 0) __hip_atomic_store(pa.flags[rl] + fidx, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (rl < pa.nranks && cl == 0) {
+            const unsigned long long* f = pa.flags[pa.rank] + ((int64_t)par * kMaxPeers + rl) * pa.nblk_cap + blockIdx.x;
+            const unsigned long long t0 = wall_clock64();
+            const bool dead = __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+            if (dead) s_timeout = 1;
+            while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > pa.timeout_ticks) {
+                    s_timeout = 1;
+                    __hip_atomic_store(pa.err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        __syncthreads();
+        if (rl < pa.nranks) {
+            double2 got = make_double2(0.0, 0.0);
+            if (valid) got = sys_load_f64x2(pa.slots[pa.rank] + ((int64_t)par * kMaxPeers + rl) * pa.cap + 2 * (int64_t)c);
+            xs[rl][cl] = got;
+            if (cl == 0) ps[rl] = __hip_atomic_load(pa.scal[pa.rank] + ((int64_t)par * kMaxPeers + rl) * pa.nblk_cap + blockIdx.x,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        // sums over ranks in rank order; sm[0] then holds the global H*p columns and rows 1.. are zero for the code below
+        double2 t = xs[0][cl];
+        double ph = ps[0];
+        for (int r = 1; r < pa.nranks; ++r) { t.x += xs[r][cl].x; t.y += xs[r][cl].y; ph += ps[r]; }
+        if (s_timeout) { ph = __longlong_as_double(0x7ff8000000000000ll); }
+        pHp = ph;
+        __syncthreads();
+        sm[rl][cl] = (rl == 0) ? t : make_double2(0.0, 0.0);
+        // the last workgroup to get here advances the exchange counter (nobody reads it again in this launch)
+        if (tid == 0) {
+            const unsigned done = atomicAdd(pa.arrive, 1u) + 1u;
+            if (done == gridDim.x) { *pa.arrive = 0u; *pa.seq = seq + 1ull; }
+        }
+    }
     const double gamma = wave_fixed_min(a.gpart, a.G);                                 // :728 / :734
     const double rtv = (a.j == 1) ? st->rtv : wave_fixed_sum(a.rvpart_in, a.nrv);      // :732  (j == 1: written by the H*p launch)
     int cont = 0, neg = 0, outside = 0;

@@ -28,6 +28,7 @@ constexpr int kPeerBlockChunks = 16;         // 16-byte chunks per workgroup of 
 struct PeerArgs {
     double* slots[kMaxPeers];                // slots[p]: base of rank p's inbox slots (own rank: the local pointer)
     unsigned long long* flags[kMaxPeers];    // flags[p]: base of rank p's inbox flags
+    double* scal[kMaxPeers];                 // scal[p]:  base of rank p's inbox scalars ([2 parities][kMaxPeers][nblk_cap])
     unsigned long long* seq;                 // local: number of exchanges executed so far + 1
     unsigned* arrive;                        // local: workgroups of the running exchange that have finished
     unsigned long long* err;                 // host-mapped: nonzero once an exchange has timed out

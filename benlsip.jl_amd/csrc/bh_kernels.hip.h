@@ -19,8 +19,8 @@
 #include "bh_reduce.hip.h"
 #include "bh_matvec.hip.h"
 #include "bh_cg.hip.h"
+#include "bh_comm.hip.h"
 #include "bh_cgfuse.hip.h"
 #include "bh_proj.hip.h"
 #include "bh_cauchy.hip.h"
-#include "bh_comm.hip.h"
 #include "bh_minor.hip.h"
