@@ -111,10 +111,11 @@ def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     assert int(z["box_mid_st"]) == int(st) and int(z["box_mid_it"]) == it, (int(z["box_mid_it"]), it)
     assert relnorm(z["box_mid_w"], w) <= 1e-8
     # kappa2 = 1e-3: ~78 iterations; on this ill-conditioned J the count itself moves by a few with the summation order
-    # (76..78 for 1e-15 relative perturbations of J in the oracle), and one iteration moves w by O(kappa2) — so compare the
-    # exit, the count within that band, and the model value the step achieves
+    # (76..80 over 24 oracle runs with 1e-15 relative perturbations of J; 75..82 on the device over 2/3/4 ranks x the two CG
+    # launch schedules, tests/multirank/tight_probe.py), and one iteration moves w by O(kappa2) — so compare the exit, the
+    # count within that band, and the model value the step achieves
     w, st, it = R.projected_cg(gm, Ho, lo_b, hi_b, box, 1e-3)
-    assert int(z["box_tight_st"]) == int(st) and abs(int(z["box_tight_it"]) - it) <= 4, (int(z["box_tight_it"]), it)
+    assert int(z["box_tight_st"]) == int(st) and abs(int(z["box_tight_it"]) - it) <= 8, (int(z["box_tight_it"]), it)
     model = lambda y: float(gm @ y + 0.5 * R.vthv(Ho, y))
     assert model(z["box_tight_w"]) == pytest.approx(model(w), rel=5e-3)      # measured 1.0e-3 with one iteration more
     assert int(z["box_tight_nh"]) > 24           # well past the first launch batch: the launch-ahead decisions were exercised
