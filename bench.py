@@ -253,7 +253,14 @@ def main():
     comm_mode = os.environ.get("BH_COMM", "rccl") if world > 1 else None
 
     def barrier():
-        bh._lib.lib().bh_synchronize()
+        bh._lib.check(bh._lib.lib().bh_synchronize(), "bh_synchronize")
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def barrier_noexcept():
+        bh._lib.lib().bh_synchronize()              # its error code (a failed peer exchange) is picked up by the caller's next call
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         if dist is not None:
@@ -275,19 +282,36 @@ def main():
     H, cons, dv, host = setup_instance(bh, rank, world, kind, strong=strong)
 
     def timed_run(steps, warmup):
-        run_steps(bh, H, cons, dv, kappa2, warmup)
-        H.reset_stats()
-        barrier()
+        """(elapsed max over ranks, (status, iters, n_hmul), stats, error).  A library error on ANY rank (e.g. a peer exchange
+        that timed out) is caught so that this rank still takes part in the barriers and the gather — otherwise the other
+        ranks would wait for it forever — and is reported to every rank alike."""
+        err, out, t0 = None, None, time.perf_counter()
+        try:
+            run_steps(bh, H, cons, dv, kappa2, warmup)
+            H.reset_stats()
+        except bh.BenlsipHipError as e:
+            err = str(e)
+        barrier_noexcept()
         t0 = time.perf_counter()
-        out = run_steps(bh, H, cons, dv, kappa2, steps)
-        barrier()
+        if err is None:
+            try:
+                out = run_steps(bh, H, cons, dv, kappa2, steps)
+            except bh.BenlsipHipError as e:
+                err = str(e)
+        barrier_noexcept()
         el = time.perf_counter() - t0
-        return float(gather([el]).max()), out, H.stats()
+        g = gather([el, 0.0 if err is None else 1.0])
+        if g[:, 1].any():
+            err = err or "a peer rank reported a library error"
+        return float(g[:, 0].max()), out, (H.stats() if err is None else None), err
 
     # short runs: time EVERY H*p launch with hipEvents (an event pair costs ~10 us of stream time, so long runs sample every 8th)
     st_probe = run_steps(bh, H, cons, dv, kappa2, 1)
     bh.set_option("profile_stride", 1 if args.steps * st_probe[2] <= 64 else 8)
-    elapsed, (status, iters, n_hmul), st = timed_run(args.steps, args.warmup)
+    elapsed, out, st, run_err = timed_run(args.steps, args.warmup)
+    if run_err is not None:                         # every rank sees the same verdict (gathered), so all of them stop here
+        raise SystemExit("bench: the timed run failed: %s" % run_err)
+    status, iters, n_hmul = out
     replicas_identical = None
     if dist is not None and world > 1:
         # Lock-step check (outside the timed region): w is replicated state, every rank must hold the SAME BITS — the
@@ -340,31 +364,54 @@ def main():
     if world > 1:
         # what the exchange costs: back-to-back all-reduces of one n-vector on the library stream (all ranks together)
         comm = {"mode": comm_mode, "timed_region_path": "rccl" if comm_mode in ("rccl", "both") else "peer_buffers", "note": comm_note}
-        try:
-            if comm_mode in ("rccl", "both"):
-                bh.set_option("comm_path", 0)
-                comm["rccl_allreduce_us"] = float(gather([1e3 * H.time_kernel(7, 200)]).max())
-                comm["rccl_reduce_plus_allreduce_us"] = float(gather([1e3 * H.time_kernel(8, 200)]).max())
-            if comm_mode in ("ipc", "both"):
-                bh.set_option("comm_path", 1)
-                comm["peer_allreduce_us"] = float(gather([1e3 * H.time_kernel(7, 200)]).max())
-                comm["peer_reduce_plus_allreduce_us"] = float(gather([1e3 * H.time_kernel(8, 200)]).max())
-                if comm_mode == "both":
-                    # the same subproblems with the exchange on the peer buffers (outside the headline's timed region)
-                    el_p, (st_p, it_p, nh_p), _ = timed_run(max(args.steps // 2, 1), 2)
-                    comm["peer_path_run"] = {"steps": max(args.steps // 2, 1), "ms_per_step": 1e3 * el_p / max(args.steps // 2, 1),
-                                             "value": max(args.steps // 2, 1) / el_p, "cg_status": st_p.name, "hmul_per_subproblem": nh_p}
-                    bh.set_option("comm_path", 0)
-        except bh.BenlsipHipError as e:
-            comm["error"] = str(e)
+        # rehearsal only: one rank skips the peer-path timing, the others run into the exchange's timeout — the failure this
+        # section has to survive without leaving a rank behind in a collective
+        fault_rank = int(os.environ.get("BH_BENCH_FAULT_RANK", "-1")) if rehearsal else -1
+
+        def timed_exchange(kind, use_peer=False):
+            """Max over ranks of bh_time_kernel(kind) in us, or None (on every rank alike) when any rank's call failed."""
             try:
-                bh.set_option("comm_path", 0)       # a timed-out peer exchange: back to RCCL for the rest of the run
-            except bh.BenlsipHipError:
-                pass
+                if fault_rank == rank and use_peer:
+                    raise bh.BenlsipHipError(-1, "bench rehearsal", "this rank stays away from the peer exchange (BH_BENCH_FAULT_RANK)")
+                v = 1e3 * H.time_kernel(kind, 200)
+            except bh.BenlsipHipError as e:
+                comm.setdefault("error", str(e))
+                v = float("nan")
+            g = gather([v])
+            if np.isnan(g).any():
+                comm.setdefault("error", "bh_time_kernel(%d) failed on rank(s) %s" % (kind, np.flatnonzero(np.isnan(g[:, 0])).tolist()))
+                return None
+            return float(g.max())
+
+        if comm_mode in ("rccl", "both"):
+            bh.set_option("comm_path", 0)
+            comm["rccl_allreduce_us"] = timed_exchange(7)
+            comm["rccl_reduce_plus_allreduce_us"] = timed_exchange(8)
+        if comm_mode in ("ipc", "both"):
+            # every decision below is taken from gathered values, so all ranks walk through the same collectives even when the
+            # peer exchange fails on some of them (it then times out, raises there and is reported as comm["error"])
+            bh.set_option("comm_path", 1)
+            comm["peer_allreduce_us"] = timed_exchange(7, True)
+            comm["peer_reduce_plus_allreduce_us"] = timed_exchange(8, True) if comm["peer_allreduce_us"] is not None else None
+            if comm_mode == "both":
+                if comm["peer_reduce_plus_allreduce_us"] is not None:
+                    # the same subproblems with the exchange on the peer buffers (outside the headline's timed region)
+                    k_p = max(args.steps // 2, 1)
+                    el_p, out_p, _, err_p = timed_run(k_p, 2)
+                    if err_p is None:
+                        comm["peer_path_run"] = {"steps": k_p, "ms_per_step": 1e3 * el_p / k_p, "value": k_p / el_p,
+                                                 "cg_status": out_p[0].name, "hmul_per_subproblem": out_p[2]}
+                    else:
+                        comm.setdefault("error", err_p)
+                try:
+                    bh.set_option("comm_path", 0)   # back to RCCL for the rest of the run (also clears a timed-out peer path)
+                except bh.BenlsipHipError as e:
+                    comm.setdefault("error", str(e))
         comm["allreduce_us"] = comm.get("rccl_allreduce_us", comm.get("peer_allreduce_us"))
         line["comm"] = comm
         line["allreduce_us"] = comm["allreduce_us"]
-    if not args.no_extras:
+    # (a peer-buffer-only run whose exchange failed has no working all-reduce left: the line is printed without the extras)
+    if not args.no_extras and not (world > 1 and comm_mode == "ipc" and line["comm"].get("error")):
         d_loc = host["hi"] - host["lo"]
         mv_bytes = 8.0 * d_loc * N_COLS + 8.0 * N_COLS + 8.0 * d_loc
         ms_f, ms_jv, ms_jtv = (H.time_kernel(k, 20) for k in (0, 1, 2))
@@ -406,7 +453,7 @@ def main():
         line["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(line), flush=True)
-    barrier()
+    barrier_noexcept()
     if dist is not None:
         H.close()                                   # handles first: the communicator cannot change under a live handle
         bh._lib.check(bh._lib.lib().bh_comm_destroy(), "bh_comm_destroy")

@@ -1271,7 +1271,7 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
     if (m == MAP_FAILED) return fail(BH_ERR_RCCL, "mmap of the rendezvous page failed");
     pc.shm = static_cast<PeerShm*>(m);
 
-    // one allocation = one handle: [slots | flags | seq, arrive].  Fine-grained (uncached) so that a peer's stores and this
+    // one allocation = one handle: [slots | flags | scal | seq, arrive, dead].  Fine-grained (uncached) so that a peer's stores and this
     // rank's polls meet in memory, not in somebody's L2.
     pc.inbox_bytes = kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes + 256;
     hipError_t e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocUncached);
@@ -1313,10 +1313,11 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
     }
     a.seq = reinterpret_cast<unsigned long long*>(base + kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes);
     a.arrive = reinterpret_cast<unsigned*>(base + kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes + 64);
+    a.dead = reinterpret_cast<unsigned*>(base + kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes + 128);
     a.err = static_cast<unsigned long long*>(dp);
     a.rank = rank; a.nranks = nranks; a.cap = kPeerCap; a.nblk_cap = kPeerBlkCap;
     const char* ts = getenv("BH_PEER_TIMEOUT_S");
-    a.timeout_ticks = (unsigned long long)(ts && atof(ts) > 0 ? atof(ts) : 20.0) * 100000000ull;     // wall_clock64: 100 MHz
+    a.timeout_ticks = (unsigned long long)((ts && atof(ts) > 0 ? atof(ts) : 20.0) * 1e8);            // wall_clock64: 100 MHz
     pc.active = true;
     return BH_OK;
 }

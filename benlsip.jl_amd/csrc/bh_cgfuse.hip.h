@@ -117,13 +117,14 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
         if (rl < pa.nranks && cl == 0) {
             const unsigned long long* f = pa.flags[pa.rank] + ((int64_t)par * kMaxPeers + rl) * pa.nblk_cap + blockIdx.x;
             const unsigned long long t0 = wall_clock64();
-            const bool dead = __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+            const bool dead = __hip_atomic_load(pa.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
             if (dead) s_timeout = 1;
             while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
                 __builtin_amdgcn_s_sleep(8);
                 if (wall_clock64() - t0 > pa.timeout_ticks) {
                     s_timeout = 1;
                     __hip_atomic_store(pa.err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(pa.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }

@@ -31,7 +31,8 @@ struct PeerArgs {
     double* scal[kMaxPeers];                 // scal[p]:  base of rank p's inbox scalars ([2 parities][kMaxPeers][nblk_cap])
     unsigned long long* seq;                 // local: number of exchanges executed so far + 1
     unsigned* arrive;                        // local: workgroups of the running exchange that have finished
-    unsigned long long* err;                 // host-mapped: nonzero once an exchange has timed out
+    unsigned long long* err;                 // host-mapped: nonzero once an exchange has timed out (written only; the host reads it)
+    unsigned* dead;                          // local copy of "an exchange has timed out" (a load from host memory costs a PCIe round trip)
     int rank, nranks;
     int64_t cap;                             // doubles per slot
     int nblk_cap;                            // flags per (parity, rank)
@@ -121,13 +122,14 @@ __global__ __launch_bounds__(256) void reduce_exchange_kernel(const double* __re
         const unsigned long long t0 = wall_clock64();
         // once an exchange has timed out the transport is considered dead: later exchanges do not wait again (the host has
         // been told through *pa.err and fails every call until the peer path is switched off)
-        const bool dead = __hip_atomic_load(pa.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+        const bool dead = __hip_atomic_load(pa.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         if (dead) s_timeout = 1;
         while (!dead && __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > pa.timeout_ticks) {     // a peer never arrived: report, never hang the device
                 s_timeout = 1;
                 __hip_atomic_store(pa.err, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(pa.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }

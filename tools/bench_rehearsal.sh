@@ -9,19 +9,23 @@ cd $R
 mkdir -p gpurun_out
 export BH_BENCH_REHEARSAL=1
 rc=0
-for cfg in "2 weak ipc" "3 strong ipc" "2 weak both"; do
+#   3. the same with rank 1 staying away from the peer exchange (BH_BENCH_FAULT_RANK): rank 0 runs into the exchange's timeout;
+#      the line must still be printed, with comm.error set and no rank left behind in a collective.
+for cfg in "2 weak ipc" "3 strong ipc" "2 weak both" "2 weak both fault"; do
     set -- $cfg
     export BH_COMM=$3
+    unset BH_BENCH_FAULT_RANK BH_PEER_TIMEOUT_S
+    if [ "$4" = "fault" ]; then export BH_BENCH_FAULT_RANK=1 BH_PEER_TIMEOUT_S=3; fi
     if [ "$3" = "both" ]; then
         g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/multirank/staged_rccl.cpp \
             -o tests/multirank/libstaged_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
         export BH_RCCL_LIB=$R/tests/multirank/libstaged_rccl.so BH_STAGED_RCCL_SHM=/bh_rehearsal_$$
     fi
     timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port 2953$1 \
-        bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2_$3.log 2>&1 || rc=$?
+        bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2_$3$4.log 2>&1 || rc=$?
     rm -f /dev/shm/bh_rehearsal_$$
-    tail -1 gpurun_out/bench_rehearsal_$1_$2_$3.log | cut -c1-1200
-    grep -o '"comm": {[^}]*}[^}]*}' gpurun_out/bench_rehearsal_$1_$2_$3.log | cut -c1-900
-    [ $rc -eq 0 ] || { tail -30 gpurun_out/bench_rehearsal_$1_$2_$3.log; exit $rc; }
+    tail -1 gpurun_out/bench_rehearsal_$1_$2_$3$4.log | cut -c1-1200
+    grep -o '"comm": {[^}]*}[^}]*}' gpurun_out/bench_rehearsal_$1_$2_$3$4.log | cut -c1-900
+    [ $rc -eq 0 ] || { tail -30 gpurun_out/bench_rehearsal_$1_$2_$3$4.log; exit $rc; }
 done
 exit $rc
