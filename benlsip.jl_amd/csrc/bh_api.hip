@@ -140,6 +140,7 @@ struct Ctx {
     int live_hess = 0;               // bh_hess handles alive (a handle bakes in this rank's share of C: see bh_comm_init)
     // dynamic-LDS ceilings already raised on this device (hipFuncSetAttribute); reset by bh_shutdown
     bool vlds_attr_set = false;      // row_stream_kernel<512,16,1,FUSED,...,VL>
+    bool cgp_vlds_attr_set = false;  // ... and its two CG-prologue symbols
     bool trsm_lds_granted = false;   // chol_trsm_kernel
     size_t trsv_lds_granted = 0;     // trsv_pair_kernel
 };
@@ -303,13 +304,12 @@ void launch_row_stream_cgp(int cfg, const RowStreamArgs& a, int grid, hipStream_
         case 5: launch_rs_cgp<512, 8, 2>(a, grid, s, expect_stop); break;
         default: {
             constexpr size_t lds = (size_t)512 * 16 * sizeof(double2);
-            static bool attr_set = false;      // (per process; bh_shutdown + bh_init keep the same code object)
-            if (!attr_set) {
+            if (!g_ctx.cgp_vlds_attr_set) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set = true;
+                g_ctx.cgp_vlds_attr_set = true;
             }
             if (expect_stop) hipLaunchKernelGGL((row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 2>), dim3(grid), dim3(512), lds, s, a);
             else hipLaunchKernelGGL((row_stream_kernel<512, 16, 1, MODE_FUSED, 1, 1, 1, 1>), dim3(grid), dim3(512), lds, s, a);
@@ -1107,7 +1107,7 @@ int32_t bh_shutdown(void) {
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.own_stream);
     g_ctx.own_stream = nullptr; g_ctx.stream = nullptr;
     if (g_pin.base) { (void)hipHostFree(g_pin.base); g_pin = PinArena(); }
-    g_ctx.vlds_attr_set = false; g_ctx.trsm_lds_granted = false; g_ctx.trsv_lds_granted = 0;
+    g_ctx.vlds_attr_set = false; g_ctx.cgp_vlds_attr_set = false; g_ctx.trsm_lds_granted = false; g_ctx.trsv_lds_granted = 0;
     g_ctx.init = false; g_ctx.rank = 0; g_ctx.nranks = 1;
     return BH_OK;
 }
@@ -1711,6 +1711,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
         // reduced form: factor A_free A_free' (mA x mA) on the device; bound changes need no host factor
         BH_TRY(ensure_reduced_buffers(P));
         BH_TRY(launch_reduced_factor(P, nfix > 0, nullptr));
+        count_d2h(sizeof(int));
         BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
     }
     BH_TRY(sync_flush());   // host vectors go out of scope
@@ -1897,7 +1898,6 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             u.n = (int)n; u.atol_neg = atol_negcurv; u.trace = a.trace; u.trace_cap = a.trace_cap; u.mirror = a.mirror; u.tag = a.tag;
             if (peer_fused) {
                 hipLaunchKernelGGL((cg_reduce_update_kernel<false, true>), dim3(nblk), dim3(256), 0, s, u, g_ctx.peer.args);
-                H->stats.n_allreduce += 1;
                 return;
             }
             if (!fuse_gen) {
@@ -1948,6 +1948,9 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
         fin_out->results_final = (mw.status == BH_CG_SOLVED || mw.status == BH_CG_MAX_ITER_REACHED || mw.status == BH_CG_NONE);
         fin_out->tag = a.tag;
+        // exchanges that really ran (one per executed H*p): how many update kernels were ENQUEUED past the exit depends on when
+        // this rank polled its progress word, and those exchange nothing
+        if (peer_fused) H->stats.n_allreduce += mw.n_hmul;
         return BH_OK;
     }
     // Box constraints with register-resident vectors: no init kernel — the first H*p forms p0 = -mask(g) on the fly and
@@ -2445,6 +2448,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     if (P->mA > 0 && g_ctx.opt_proj_form == 0)
         return fail(BH_ERR_UNSUPPORTED, "bh_cauchy_step needs the reduced projection form (proj_form = 1)");
     const int64_t n = H->n;
+    if (n + 1 >= 0xfffff) return fail(BH_ERR_UNSUPPORTED, "n exceeds the 20-bit pass counter of the progress word");
     const int mA = (int)P->mA;
     BH_TRY(ensure_cg_workspace(H->ld, 0));
     CgWorkspace& c = g_ctx.cg;
@@ -2477,7 +2481,6 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     P->active_set = false;             // device mask is authoritative until adopt_mask below
     hipLaunchKernelGGL(cauchy_init_kernel, dim3(1), dim3(CG_T), 0, s, a);
     if (mA > 0) BH_TRY(launch_reduced_factor(P, true, nullptr));
-    if (n + 1 >= 0xfffff) return fail(BH_ERR_UNSUPPORTED, "n exceeds the 20-bit pass counter of the progress word");
     const int max_pass = (int)(n + 1);
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
@@ -2577,6 +2580,8 @@ int32_t bh_dev_alloc(void** out, int64_t bytes) {
 int32_t bh_dev_free(void* p) { dev_free(p); return BH_OK; }
 int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
     BH_REQUIRE_INIT();
+    if (bytes < 0 || (bytes > 0 && (!dst_dev || !src_host))) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    if (bytes == 0) return BH_OK;
     count_h2d((size_t)bytes);
     BH_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, g_ctx.stream));
     BH_TRY(sync_flush());
@@ -2584,6 +2589,8 @@ int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
 }
 int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
     BH_REQUIRE_INIT();
+    if (bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) return fail(BH_ERR_INVALID_ARG, "bad argument");
+    if (bytes == 0) return BH_OK;
     count_d2h((size_t)bytes);
     BH_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     BH_TRY(sync_flush());
@@ -2611,9 +2618,13 @@ int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
     if (!H || !avg_ms || reps < 1 || kind < 0 || kind > 8) return fail(BH_ERR_INVALID_ARG, "bad argument");
     BH_TRY(hess_ready(H));
     if (kind == 7 && !comm_active()) return fail(BH_ERR_PRECONDITION, "bh_time_kernel(7): no communicator (bh_comm_init; BH_FORCE_COMM=1 for one rank)");
-    hipEvent_t e0, e1;
-    BH_HIP(hipEventCreate(&e0));
-    BH_HIP(hipEventCreate(&e1));
+    struct EventPair {          // destroyed on every way out of this function
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } evp;
+    BH_HIP(hipEventCreate(&evp.a));
+    BH_HIP(hipEventCreate(&evp.b));
+    const hipEvent_t e0 = evp.a, e1 = evp.b;
     if (kind >= 7) {
         // 7: the all-reduce of one n-vector on the active communicator path; 8: everything an H*p does after its streaming
         // kernel (slab reduction + exchange).  Back-to-back launches between two events: all ranks must call this together.
@@ -2627,8 +2638,6 @@ int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
         if (rc == BH_OK && hipEventSynchronize(e1) != hipSuccess) rc = fail(BH_ERR_HIP, "hipEventSynchronize");
         float ms = 0.f;
         if (rc == BH_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = fail(BH_ERR_HIP, "hipEventElapsedTime");
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         if (rc == BH_OK) rc = check_peer_error();
         if (rc != BH_OK) return rc;
         *avg_ms = ms / reps;
@@ -2649,8 +2658,6 @@ int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
             BH_HIP(hipEventElapsedTime(&ms, e0, e1));
             if (i >= 0) total += ms;
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         *avg_ms = total / reps;
         return BH_OK;
     }
@@ -2674,8 +2681,6 @@ int32_t bh_time_kernel(bh_hess* H, int32_t kind, int32_t reps, double* avg_ms) {
         BH_HIP(hipEventElapsedTime(&ms, e0, e1));
         total += ms;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *avg_ms = total / reps;
     return BH_OK;
 }
