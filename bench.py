@@ -312,14 +312,18 @@ def main():
     if run_err is not None:                         # every rank sees the same verdict (gathered), so all of them stop here
         raise SystemExit("bench: the timed run failed: %s" % run_err)
     status, iters, n_hmul = out
-    replicas_identical = None
-    if dist is not None and world > 1:
-        # Lock-step check (outside the timed region): w is replicated state, every rank must hold the SAME BITS — the
-        # launch-ahead schedule relies on it.  Compare a checksum of the bit patterns across ranks.
-        bits = dv["w"].download().view(np.int64)
-        chk = float(int(np.bitwise_xor.reduce(bits)) % (1 << 52)) + float(iters) * 1e-3 + float(n_hmul) * 1e-6
+    def replica_check(it_, nh_):
+        """Lock-step check (outside the timed region): w is replicated state, every rank must hold the SAME BITS — the
+        launch-ahead schedule relies on it.  Compares a checksum of the bit patterns across ranks; returns
+        (identical, this rank's w)."""
+        w_host = dv["w"].download()
+        chk = float(int(np.bitwise_xor.reduce(w_host.view(np.int64))) % (1 << 52)) + float(it_) * 1e-3 + float(nh_) * 1e-6
         allchk = gather([chk])
-        replicas_identical = bool(np.all(allchk == allchk[0]))
+        return bool(np.all(allchk == allchk[0])), w_host
+
+    replicas_identical, w_headline = None, None
+    if dist is not None and world > 1:
+        replicas_identical, w_headline = replica_check(iters, n_hmul)
 
     traffic, traffic_src = pmc_traffic() if world == 1 else (None, None)
     ms_per_step = 1e3 * elapsed / args.steps
@@ -399,8 +403,13 @@ def main():
                     k_p = max(args.steps // 2, 1)
                     el_p, out_p, _, err_p = timed_run(k_p, 2)
                     if err_p is None:
+                        # the peer path must agree with itself across ranks (bits) and with the RCCL run (same subproblem, the sum
+                        # over ranks taken in another order: rounding-level difference)
+                        ident_p, w_peer = replica_check(out_p[1], out_p[2])
+                        rel = float(np.linalg.norm(w_peer - w_headline) / max(np.linalg.norm(w_headline), 1e-300))
                         comm["peer_path_run"] = {"steps": k_p, "ms_per_step": 1e3 * el_p / k_p, "value": k_p / el_p,
-                                                 "cg_status": out_p[0].name, "hmul_per_subproblem": out_p[2]}
+                                                 "cg_status": out_p[0].name, "hmul_per_subproblem": out_p[2],
+                                                 "replicas_bitwise_identical": ident_p, "w_rel_diff_vs_rccl_run": rel}
                     else:
                         comm.setdefault("error", err_p)
                 try:
