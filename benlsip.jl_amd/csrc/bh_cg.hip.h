@@ -67,6 +67,30 @@ __device__ __forceinline__ void publish_state(const CgArgs& a, const CgState* st
     __hip_atomic_store(a.mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The same word (and, when done, the tie log) from values the caller holds in registers.
+__device__ __forceinline__ void publish_word(unsigned long long* mirror, unsigned tag, int status, int done, int iter, int n_hmul,
+                                             const TieRegs& tr) {
+    if (mirror == nullptr) return;
+    const unsigned long long wv = ((unsigned long long)(tag & 0xffffu) << 48) | ((unsigned long long)(status & 0xf) << 44) |
+                                  ((unsigned long long)(done & 0xf) << 40) | ((unsigned long long)(iter & 0xfffff) << 20) |
+                                  (unsigned long long)(n_hmul & 0xfffff);
+    if (done) {
+        const unsigned long long tw = ((unsigned long long)(tr.margin_kind & 0xf) << 48) | ((unsigned long long)(tr.tie_flags & 0xff) << 40) |
+                                      ((unsigned long long)(tr.tie_first & 0xfffff) << 20) | (unsigned long long)(tr.margin_at & 0xfffff);
+        __hip_atomic_store(mirror + 1, tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(mirror + 2, (unsigned long long)__double_as_longlong(tr.min_margin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// cg_final_status (:753-761) on register values
+__device__ __forceinline__ int cg_status_of(int approx_solved, int outside_region, int neg_curvature, int iter, int max_iter) {
+    if (approx_solved) return 0;
+    if (outside_region) return 1;
+    if (neg_curvature) return 2;
+    if (iter == max_iter) return 3;
+    return 4;
+}
+
 // w = 0; r = g  (:702-705).  With BOX: v = mask(r), then the tail of cg_init_finish.
 template <bool BOX>
 __global__ __launch_bounds__(CG_T) void cg_init_kernel(CgArgs a) {

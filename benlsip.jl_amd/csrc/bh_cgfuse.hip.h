@@ -65,30 +65,43 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
     const int64_t ld2 = a.ld >> 1;
     const double QNAN = __longlong_as_double(0x7ff8000000000000ll);
 
-    // ---- this workgroup's 32 columns of Hp = sum of the slabs (fixed order) --------------------------------------------
-    const double2* P2 = reinterpret_cast<const double2*>(a.partials);
-    double2 acc = make_double2(0.0, 0.0);
-    if (valid) {
-        int g = rl;
-        for (; g + 48 < a.G; g += 64) {
-            const double2 x0 = P2[(int64_t)g * ld2 + c];
-            const double2 x1 = P2[(int64_t)(g + 16) * ld2 + c];
-            const double2 x2 = P2[(int64_t)(g + 32) * ld2 + c];
-            const double2 x3 = P2[(int64_t)(g + 48) * ld2 + c];
-            acc.x += x0.x; acc.y += x0.y;
-            acc.x += x1.x; acc.y += x1.y;
-            acc.x += x2.x; acc.y += x2.y;
-            acc.x += x3.x; acc.y += x3.y;
-        }
-        for (; g < a.G; g += 16) {
-            const double2 x0 = P2[(int64_t)g * ld2 + c];
-            acc.x += x0.x; acc.y += x0.y;
+    // ---- every load the kernel needs goes out first: the iteration's partial sums, this workgroup's slab rows, its vector
+    //      entries.  The kernel is latency-bound (a few hundred bytes per thread); issued one reduction at a time the same
+    //      loads cost ~15 dependent memory round trips, issued together ~2.
+    const bool upd = (rl == 0) && valid;                       // the 16 threads that update this workgroup's 16 chunks
+    const bool from_g = (a.j == 1 && !a.init_in_memory);      // r = g_minor (:705), w = 0 (:702)
+    double2 pk = make_double2(0.0, 0.0), wk = pk, hwk = pk, rk = pk;
+    int2 fr = make_int2(-1, -1);
+    if (upd) {
+        pk = reinterpret_cast<const double2*>(a.p)[c];
+        if (from_g) {
+            rk = reinterpret_cast<const double2*>(a.g)[c];
+        } else {
+            rk = reinterpret_cast<const double2*>(a.r)[c];
+            wk = reinterpret_cast<const double2*>(a.w)[c];
+            if (a.hw != nullptr) hwk = reinterpret_cast<const double2*>(a.hw)[c];
         }
     }
+    TieRegs tr;                                                // (uniform: every thread holds the log, one of them commits it)
+    tr.load(st);
+    const int max_iter = st->max_iter;
+    const double rtv_state = st->rtv;                          // j == 1: written by the H*p launch
+    LaneBatch<8> b_sq, b_gp, b_rv;
+    b_sq.issue(a.sqpart, a.G);
+    b_gp.issue(a.gpart, a.G);
+    b_rv.issue(a.rvpart_in, a.nrv);                            // (j == 1: addressable, not used)
+    const double2* P2 = reinterpret_cast<const double2*>(a.partials);
+    const int cc = min(c, a.nchunks - 1);                      // out-of-range threads load a valid chunk and drop the result:
+    SlabBatch sb;                                              // no branch around the loads (see LaneBatch::issue)
+    sb.issue(P2, ld2, cc, rl, a.G);
+    if (upd && a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[c];   // last: its compare is scheduled next to it
+
+    // ---- this workgroup's 32 columns of Hp = sum of the slabs (fixed order) --------------------------------------------
+    const double2 acc = sb.fold(P2, ld2, cc, rl, a.G);
     sm[rl][cl] = acc;
 
     // ---- the iteration's scalars, recomputed by every wave from the partials (identical bits everywhere) -----------------
-    double pHp = wave_fixed_sum(a.sqpart, a.G);                                        // :723 (this rank's rows)
+    double pHp = wave_sum(b_sq.fold_sum(a.sqpart, a.G));                               // :723 (this rank's rows)
     if (PEER) {
         __shared__ int s_timeout;
         __shared__ double2 xs[kMaxPeers][16];
@@ -153,8 +166,8 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
             if (done == gridDim.x) { *pa.arrive = 0u; *pa.seq = seq + 1ull; }
         }
     }
-    const double gamma = wave_fixed_min(a.gpart, a.G);                                 // :728 / :734
-    const double rtv = (a.j == 1) ? st->rtv : wave_fixed_sum(a.rvpart_in, a.nrv);      // :732  (j == 1: written by the H*p launch)
+    const double gamma = wave_min(b_gp.fold_min(a.gpart, a.G));                        // :728 / :734
+    const double rtv = (a.j == 1) ? rtv_state : wave_sum(b_rv.fold_sum(a.rvpart_in, a.nrv));   // :732
     int cont = 0, neg = 0, outside = 0;
     double step = 0.0, alpha = QNAN;
     bool add_w = true;
@@ -179,17 +192,6 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
         // Every vector here is either the caller's buffer with n == 2*nchunks or a zero-padded workspace vector: whole 16-byte
         // chunks are always addressable.  Elements at or beyond n are kept at exactly 0 (never updated: Inf*0 would poison them).
         const bool e0 = 2 * c < a.n, e1 = 2 * c + 1 < a.n;
-        const double2 pk = reinterpret_cast<const double2*>(a.p)[c];
-        double2 wk = make_double2(0.0, 0.0), hwk = make_double2(0.0, 0.0), rk;
-        if (a.j == 1 && !a.init_in_memory) {
-            rk = reinterpret_cast<const double2*>(a.g)[c];           // r = g_minor (:705), w = 0 (:702)
-        } else {
-            rk = reinterpret_cast<const double2*>(a.r)[c];
-            wk = reinterpret_cast<const double2*>(a.w)[c];
-            if (a.hw != nullptr) hwk = reinterpret_cast<const double2*>(a.hw)[c];
-        }
-        int2 fr = make_int2(-1, -1);
-        if (a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[c];
         if (add_w) {
             wk.x = __dadd_rn(wk.x, __dmul_rn(step, pk.x));           // :729 / :737 / :739
             wk.y = __dadd_rn(wk.y, __dmul_rn(step, pk.y));
@@ -252,18 +254,19 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
     if (blockIdx.x == 0 && tid == 0) {
         st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = a.j; st->rtv = rtv;
         st->neg_curvature = neg; st->outside_region = outside; st->need_proj = 0; st->iter = a.j;
-        tie_note_step_a(st, pHp, a.atol_neg, alpha, gamma, a.j);
+        tr.note_step_a(pHp, a.atol_neg, alpha, gamma, a.j);
+        tr.store(st);
         if (a.trace != nullptr && a.j <= a.trace_cap) {
             double* row = a.trace + 4 * (int64_t)(a.j - 1);
             row[0] = pHp; row[1] = alpha; row[2] = (neg && !add_w) ? QNAN : gamma; row[3] = rtv;   // [3]: r.v after :746 follows in the next launch
         }
+        int status = 4;                          // (a progress word: the host reads the status of a finished loop only)
         if (!cont) {
+            status = cg_status_of(0, outside, neg, a.j, max_iter);
             st->approx_solved = 0; st->done = 1; st->stop_at = a.j;
-            st->status = cg_final_status(st);
+            st->status = status;
         }
-        CgArgs pa{};
-        pa.mirror = a.mirror; pa.tag = a.tag;
-        publish_state(pa, st);                  // progress (n_hmul = j) or the final state
+        publish_word(a.mirror, a.tag, status, cont ? 0 : 1, a.j, a.j, tr);      // progress (n_hmul = j) or the final state
     }
 }
 

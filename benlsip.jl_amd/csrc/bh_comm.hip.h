@@ -71,23 +71,10 @@ __global__ __launch_bounds__(256) void reduce_exchange_kernel(const double* __re
     double2 acc = make_double2(0.0, 0.0);
     if (G > 0) {
         const double2* P2 = reinterpret_cast<const double2*>(partials);
-        if (valid) {
-            int g = rl;
-            for (; g + 48 < G; g += 64) {
-                const double2 x0 = P2[(int64_t)g * ld2 + c];
-                const double2 x1 = P2[(int64_t)(g + 16) * ld2 + c];
-                const double2 x2 = P2[(int64_t)(g + 32) * ld2 + c];
-                const double2 x3 = P2[(int64_t)(g + 48) * ld2 + c];
-                acc.x += x0.x; acc.y += x0.y;
-                acc.x += x1.x; acc.y += x1.y;
-                acc.x += x2.x; acc.y += x2.y;
-                acc.x += x3.x; acc.y += x3.y;
-            }
-            for (; g < G; g += 16) {
-                const double2 x0 = P2[(int64_t)g * ld2 + c];
-                acc.x += x0.x; acc.y += x0.y;
-            }
-        }
+        const int cc = min(c, nchunks - 1);    // out-of-range threads load a valid chunk and drop the result
+        SlabBatch sb;
+        sb.issue(P2, ld2, cc, rl, G);
+        acc = sb.fold(P2, ld2, cc, rl, G);
         sm[rl][cl] = acc;
         __syncthreads();
         if (rl == 0) {

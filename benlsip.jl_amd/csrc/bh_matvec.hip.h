@@ -26,7 +26,7 @@ struct CgFuse {
     int n, max_iter;
     const double* vvec;     // v = P(r) after iteration j-1                (j >= 2)
     const double* p_old;    // p_{j-1}                                     (j >= 2)
-    double* p_new;          // p_j: every workgroup stores the chunks it owns (chunk c belongs to workgroup c % gridDim.x)
+    double* p_new;          // p_j: every workgroup stores the chunks it owns (run c / CPT of consecutive chunks belongs to workgroup (c / CPT) % gridDim.x)
     const double* rvpart;   // partial sums of r.v written by cg_reduce_update_kernel(j-1)
     int nrv;
     const double* w;        // w after iteration j-1 (j == 1: w = 0)
@@ -190,17 +190,22 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     if (!CGP || a.cf.j == 1) {
         // the first row group does not depend on the vector: its loads go out first
         if (PF && g < ngroups) load_group(A, g);
+        // (all loads first, the masking afterwards: a compare next to its load makes the compiler wait for each chunk in turn)
+        int2 nm[CPT];
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int c = tid + k * T;
+            nm[k] = make_int2(-1, -1);
             if (MODE != MODE_JTV && act[k]) {
                 vv[k] = reinterpret_cast<const double2*>(a.v)[c];
-                if (a.negate) {
-                    int2 f = make_int2(-1, -1);
-                    if (a.negmask != nullptr) f = reinterpret_cast<const int2*>(a.negmask)[c];
-                    vv[k].x = (f.x >= 0) ? 0.0 : -vv[k].x;
-                    vv[k].y = (f.y >= 0) ? 0.0 : -vv[k].y;
-                }
+                if (a.negate && a.negmask != nullptr) nm[k] = reinterpret_cast<const int2*>(a.negmask)[c];
+            }
+        }
+        if (MODE != MODE_JTV && a.negate) {
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                vv[k].x = (nm[k].x >= 0) ? 0.0 : -vv[k].x;
+                vv[k].y = (nm[k].y >= 0) ? 0.0 : -vv[k].y;
             }
         }
     }
@@ -233,7 +238,11 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 __syncthreads();                                   // pro[] is reused below
             }
         } else {
-            // loads of the prologue first (they come back in ~1 us from L2), the first row group of J right behind them
+            // CGP = 1 (expected to go on): the first row group of J goes out FIRST — loads return in order, so the prologue's own
+            // operands (v, p, the r.v partials: L2 hits) arrive right behind it and the prologue's arithmetic runs while nothing
+            // else is outstanding; issued the other way round the stream would start one memory round trip later.  If the loop
+            // turns out to have stopped, the 128 KiB this workgroup asked for are simply dropped.
+            if (CGP != 2 && PF && g < ngroups) load_group(A, g);
             double2 vk[CPT], po[CPT];
 #pragma unroll
             for (int k = 0; k < CPT; ++k) {
@@ -243,24 +252,29 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                     po[k] = reinterpret_cast<const double2*>(f.p_old)[tid + k * T];
                 }
             }
-            const double rtv_next = wave_fixed_sum(f.rvpart, f.nrv);          // :743, same bits in every wave of every workgroup
             const double rtv = st->rtv, tol_cg = st->tol_cg;
-            if (CGP != 2 && PF && g < ngroups) load_group(A, g);
+            TieRegs tr;                                                        // (uniform loads, issued with the rest)
+            tr.load(st);
+            const int outside_prev = st->outside_region, neg_prev = st->neg_curvature;
+            const double rtv_next = wave_fixed_sum(f.rvpart, f.nrv);          // :743, same bits in every wave of every workgroup
             const bool solved = fabs(rtv_next) < tol_cg;                       // :747
             const bool stop = solved || f.j > f.max_iter;                      // :720 with iter = j after :748
             const double beta = __ddiv_rn(rtv_next, rtv);                      // :744
             if (blockIdx.x == 0 && tid == 0) {
-                tie_note(st, TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), f.j - 1);
+                // everything below works on registers: this thread's workgroup starts streaming only when it is through
+                tr.note(TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), f.j - 1);
+                tr.store(st);
                 if (f.trace != nullptr && f.j - 1 <= f.trace_cap) f.trace[4 * (int64_t)(f.j - 2) + 3] = rtv_next;
                 st->iter = f.j;                        // :748 (nobody reads it back: the kernels count iterations by launch)
+                int status = 4;
                 if (stop) {
+                    status = cg_status_of(solved ? 1 : 0, outside_prev, neg_prev, f.j, f.max_iter);
                     st->beta = beta; st->rtv = rtv_next; st->approx_solved = solved ? 1 : 0;
                     st->done = 1; st->stop_at = f.j - 1;
-                    st->status = cg_final_status(st);
+                    st->status = status;
                 }
-                CgArgs pa{};
-                pa.mirror = f.mirror; pa.tag = f.tag;
-                publish_state(pa, st);                 // "stopped after iteration j-1", or "iter = j: iteration j is streaming"
+                // "stopped after iteration j-1", or "iter = j: iteration j is streaming" (n_hmul = j - 1 either way)
+                publish_word(f.mirror, f.tag, status, stop ? 1 : 0, f.j, f.j - 1, tr);
             }
             if (stop) return;
             if (CGP == 2 && PF && g < ngroups) load_group(A, g);              // the prediction was wrong: carry on
@@ -270,14 +284,17 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
                 vv[k].y = __dadd_rn(-vk[k].y, __dmul_rn(beta, po[k].y));
             }
         }
-        // the chunks this workgroup owns (chunk c belongs to workgroup c % gridDim.x): store p_j; the workgroup's share of
-        // gamma = factor_to_boundary(p, w, w_l, w_u) (:734 / :728)
+        // the chunks this workgroup owns: store p_j; the workgroup's share of gamma = factor_to_boundary(p, w, w_l, w_u)
+        // (:734 / :728).  Ownership goes by RUNS of CPT consecutive chunks (run r belongs to workgroup r % gridDim.x): a
+        // workgroup's chunks then sit in CPT neighbouring lanes of one k — one round trip for their w, w_l, w_u.  (Dealt out
+        // chunk by chunk, c % gridDim.x, one lane owned a chunk in every k and walked through CPT dependent round trips
+        // while the rest of the workgroup waited at the barrier below: ~4 us per launch at n = 4096.)
         OpMinNan opmin;
         double gm = __longlong_as_double(0x7ff0000000000000ll);
 #pragma unroll
         for (int k = 0; k < CPT; ++k) {
             const int c = tid + k * T;
-            if (!act[k] || (c % (int)G) != (int)blockIdx.x) continue;
+            if (!act[k] || ((c / CPT) % (int)G) != (int)blockIdx.x) continue;
             reinterpret_cast<double2*>(f.p_new)[c] = vv[k];
             double2 wk = make_double2(0.0, 0.0);
             if (f.j > 1) wk = reinterpret_cast<const double2*>(f.w)[c];
@@ -341,24 +358,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
     const int c = blockIdx.x * 16 + cl;
     const int64_t ld2 = ld >> 1;
     const double2* P2 = reinterpret_cast<const double2*>(partials);
-    double2 acc = make_double2(0.0, 0.0);
-    if (c < nchunks) {
-        int g = rl;
-        for (; g + 48 < G; g += 64) {
-            const double2 x0 = P2[(int64_t)g * ld2 + c];
-            const double2 x1 = P2[(int64_t)(g + 16) * ld2 + c];
-            const double2 x2 = P2[(int64_t)(g + 32) * ld2 + c];
-            const double2 x3 = P2[(int64_t)(g + 48) * ld2 + c];
-            acc.x += x0.x; acc.y += x0.y;
-            acc.x += x1.x; acc.y += x1.y;
-            acc.x += x2.x; acc.y += x2.y;
-            acc.x += x3.x; acc.y += x3.y;
-        }
-        for (; g < G; g += 16) {
-            const double2 x0 = P2[(int64_t)g * ld2 + c];
-            acc.x += x0.x; acc.y += x0.y;
-        }
-    }
+    const int cc = min(c, nchunks - 1);        // out-of-range threads load a valid chunk and drop the result (no branch around the loads)
+    SlabBatch sb;
+    sb.issue(P2, ld2, cc, rl, G);
+    const double2 acc = sb.fold(P2, ld2, cc, rl, G);
     sm[rl][cl] = acc;
     __syncthreads();
     if (rl == 0 && c < nchunks) {

@@ -110,17 +110,72 @@ struct CgState {
 
 // Sum / min of m doubles by ONE wave in an order that does not depend on the workgroup shape: lane l folds x[l], x[l+64], ...
 // in index order, then the fixed butterfly.  Every wave (of any kernel) that calls it on the same data gets the same bits.
+// The loads of the first 64*B entries go out together (issue), the adds follow in index order (fold): one memory round trip
+// instead of one per 64 entries — these reductions sit on the critical path of latency-bound kernels.  A caller with several
+// reductions issues all of them before folding any.
+template <int B>
+struct LaneBatch {
+    double t[B];
+    // (unconditional loads from clamped indices: a load under the same predicate as its add invites the compiler to fuse the
+    // two and wait for the data on the spot, which serialises the batch again)
+    __device__ __forceinline__ void issue(const double* __restrict__ x, int m) {
+        const int lane = threadIdx.x & 63, last = max(m - 1, 0);      // x holds at least one addressable element
+#pragma unroll
+        for (int k = 0; k < B; ++k) t[k] = x[min(lane + 64 * k, last)];
+    }
+    __device__ __forceinline__ double fold_sum(const double* __restrict__ x, int m) const {
+        const int lane = threadIdx.x & 63;
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < B; ++k) if (lane + 64 * k < m) acc += t[k];
+        for (int i = lane + 64 * B; i < m; i += 64) acc += x[i];
+        return acc;
+    }
+    __device__ __forceinline__ double fold_min(const double* __restrict__ x, int m) const {
+        const int lane = threadIdx.x & 63;
+        OpMinNan op;
+        double acc = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll
+        for (int k = 0; k < B; ++k) if (lane + 64 * k < m) acc = op(acc, t[k]);
+        for (int i = lane + 64 * B; i < m; i += 64) acc = op(acc, x[i]);
+        return acc;
+    }
+};
 __device__ __forceinline__ double wave_fixed_sum(const double* __restrict__ x, int m) {
-    double acc = 0.0;
-    for (int i = threadIdx.x & 63; i < m; i += 64) acc += x[i];
-    return wave_sum(acc);
+    LaneBatch<8> b;
+    b.issue(x, m);
+    return wave_sum(b.fold_sum(x, m));
 }
 __device__ __forceinline__ double wave_fixed_min(const double* __restrict__ x, int m) {
-    OpMinNan op;
-    double acc = __longlong_as_double(0x7ff0000000000000ll);
-    for (int i = threadIdx.x & 63; i < m; i += 64) acc = op(acc, x[i]);
-    return wave_min(acc);
+    LaneBatch<8> b;
+    b.issue(x, m);
+    return wave_min(b.fold_min(x, m));
 }
+
+// Column sums of the partial slabs a row-stream launch left: thread (rl, c) of a 16 x 16 arrangement folds slab rows rl, rl+16,
+// rl+32, ... of 16-byte chunk c in ascending row order.  As above the loads go out 16 at a time (256 slab rows per round trip).
+struct SlabBatch {
+    double2 x[16];
+    __device__ __forceinline__ void issue(const double2* __restrict__ P2, int64_t ld2, int c, int rl, int G) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = P2[(int64_t)min(rl + 16 * k, G - 1) * ld2 + c];      // G >= 1; clamped as in LaneBatch
+    }
+    __device__ __forceinline__ double2 fold(const double2* __restrict__ P2, int64_t ld2, int c, int rl, int G) const {
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (rl + 16 * k < G) { acc.x += x[k].x; acc.y += x[k].y; }
+        for (int g0 = rl + 256; g0 < G; g0 += 256) {            // more than 256 slab rows (several workgroups per CU): batch by batch
+            double2 y[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) y[k] = P2[(int64_t)min(g0 + 16 * k, G - 1) * ld2 + c];
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (g0 + 16 * k < G) { acc.x += y[k].x; acc.y += y[k].y; }
+        }
+        return acc;
+    }
+};
 
 // Branch tests of projected_cg whose outcome can flip under rounding (src/basic_tralcnlss.jl:725, :727, :735, :747).
 enum { TIE_NEGCURV = 1, TIE_NEGCURV_ABS = 2, TIE_BOUND = 4, TIE_TOL = 8 };
@@ -145,6 +200,32 @@ __device__ __forceinline__ void tie_note_step_a(CgState* st, double pHp, double 
     if (pHp <= atol_neg) tie_note(st, TIE_NEGCURV_ABS, rel_margin(fabs(pHp), atol_neg), n_hmul);
     else tie_note(st, TIE_BOUND, rel_margin(alpha, gamma), n_hmul);
 }
+
+// The same log kept in registers by the two-kernel iteration: its kernels load the five words up front together with everything
+// else they need (the log lives in CgState, last written by the PREVIOUS launch), note in registers and store once — the
+// memory-resident form above costs a dependent load per field on the single thread that commits an iteration, and that thread's
+// workgroup is on the critical path of its launch.
+struct TieRegs {
+    double min_margin;
+    int margin_kind, margin_at, tie_flags, tie_first;
+    __device__ __forceinline__ void load(const CgState* st) {
+        min_margin = st->min_margin; margin_kind = st->margin_kind; margin_at = st->margin_at;
+        tie_flags = st->tie_flags; tie_first = st->tie_first;
+    }
+    __device__ __forceinline__ void note(int kind, double margin, int n_hmul) {
+        if (margin < min_margin) { min_margin = margin; margin_kind = kind; margin_at = n_hmul; }
+        if (margin <= kTieRel) { tie_flags |= kind; if (tie_first == 0) tie_first = n_hmul; }
+    }
+    __device__ __forceinline__ void note_step_a(double pHp, double atol_neg, double alpha, double gamma, int n_hmul) {
+        note(TIE_NEGCURV, rel_margin(pHp, atol_neg), n_hmul);
+        if (pHp <= atol_neg) note(TIE_NEGCURV_ABS, rel_margin(fabs(pHp), atol_neg), n_hmul);
+        else note(TIE_BOUND, rel_margin(alpha, gamma), n_hmul);
+    }
+    __device__ __forceinline__ void store(CgState* st) const {
+        st->min_margin = min_margin; st->margin_kind = margin_kind; st->margin_at = margin_at;
+        st->tie_flags = tie_flags; st->tie_first = tie_first;
+    }
+};
 
 // Self-test of the wave reduction network (bh_selftest): out[wave] = sum, out[16 + wave] = min.
 __global__ __launch_bounds__(256) void selftest_wave_kernel(const double* in, double* out) {
