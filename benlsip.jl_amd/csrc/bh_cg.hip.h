@@ -305,6 +305,11 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
     const int nch = (a.n + 1) >> 1;
     double rtv = FIRST ? 0.0 : st->rtv, tol_cg = FIRST ? 0.0 : st->tol_cg;
     const int iter0 = FIRST ? 1 : st->iter, max_iter = FIRST ? a.max_iter : st->max_iter, n_hmul0 = FIRST ? 0 : st->n_hmul;
+    // the tie log travels in registers (loaded here with everything else, stored once by the committing thread): kept in memory
+    // it costs that thread a dependent load per field at the very end of a single-workgroup kernel
+    TieRegs tr;
+    if (FIRST) { tr.min_margin = __longlong_as_double(0x7ff0000000000000ll); tr.margin_kind = 0; tr.margin_at = 0; tr.tie_flags = 0; tr.tie_first = 0; }
+    else tr.load(st);
 
     bool act[CH];
     double2 p[CH], hp[CH], w[CH], wl[CH], wu[CH], r[CH], v[CH];
@@ -471,36 +476,42 @@ __global__ __launch_bounds__(CG_T) void cg_step_reg_kernel(CgArgs a) {
     if (tid == 0) {
         const int n_hmul = (PHASE == 2) ? n_hmul0 : n_hmul0 + 1;
         bool write_trace = false;
+        int done = 0, status = 4, iter = iter0;       // (status of a progress word: the host reads it of a finished loop only)
         if (FIRST) {
             st->rtv = rtv; st->tol_cg = tol_cg; st->beta = 0.0;
             st->iter = 1; st->max_iter = max_iter; st->approx_solved = 0; st->done = 0; st->status = 4;
-            tie_reset(st);
         }
         if (PHASE != 2) {
             st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = n_hmul;
             st->neg_curvature = neg; st->outside_region = outside;
-            tie_note_step_a(st, pHp, a.atol_neg, alpha, gamma, n_hmul);
+            tr.note_step_a(pHp, a.atol_neg, alpha, gamma, n_hmul);
             st->need_proj = (PHASE == 1 && cont) ? 1 : 0;
             if (!cont) {
-                st->done = 1;
-                st->status = cg_final_status(st);
+                // approx_solved is 0 here: a loop that had met :747 would have stopped before this pass
+                done = 1;
+                status = cg_status_of(0, outside, neg, iter0, max_iter);
                 write_trace = true;
             }
         }
         if (cont && PHASE != 1) {
+            const int approx = fabs(rtv_next) < tol_cg ? 1 : 0;            // :747
             st->beta = beta; st->rtv = rtv_next;                           // :746
-            st->approx_solved = fabs(rtv_next) < tol_cg;                   // :747
-            tie_note(st, TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), n_hmul);
-            st->iter = iter0 + 1;                                          // :748
+            st->approx_solved = approx;
+            tr.note(TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), n_hmul);
+            iter = iter0 + 1;                                              // :748
+            st->iter = iter;
             st->need_proj = 0;
-            if (st->approx_solved || st->iter > max_iter) { st->done = 1; st->status = cg_final_status(st); }
+            // (the pass continued: neither outside_region nor neg_curvature is set — step_a of this iteration cleared them)
+            if (approx || iter > max_iter) { done = 1; status = cg_status_of(approx, 0, 0, iter, max_iter); }
             write_trace = true;
         }
+        if (done) { st->done = 1; st->status = status; }
+        tr.store(st);
         if (write_trace && a.trace != nullptr && n_hmul <= a.trace_cap) {
             double* row = a.trace + 4 * (int64_t)(n_hmul - 1);
             row[0] = pHp; row[1] = alpha; row[2] = (PHASE != 2 && neg && !add_w) ? QNAN : gamma; row[3] = rtv_next;
         }
-        if (write_trace) publish_state(a, st);     // an iteration (or the whole loop) has completed
+        if (write_trace) publish_word(a.mirror, a.tag, status, done, iter, n_hmul, tr);     // an iteration (or the whole loop) has completed
     }
 }
 

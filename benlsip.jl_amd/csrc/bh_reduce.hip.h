@@ -177,6 +177,13 @@ struct SlabBatch {
     }
 };
 
+// x where the variable is free (rank < 0), +0.0 where it is fixed — as a bit mask instead of a compare + select: a compare on a
+// freshly loaded word is scheduled right behind its load (with the wait), which serialises a batch of loads again.
+__device__ __forceinline__ double keep_if_free(double x, int rank) {
+    const long long keep = (long long)(rank >> 31);            // rank < 0: all ones; rank >= 0: zero
+    return __longlong_as_double(__double_as_longlong(x) & keep);
+}
+
 // Branch tests of projected_cg whose outcome can flip under rounding (src/basic_tralcnlss.jl:725, :727, :735, :747).
 enum { TIE_NEGCURV = 1, TIE_NEGCURV_ABS = 2, TIE_BOUND = 4, TIE_TOL = 8 };
 constexpr double kTieRel = 1e-10;
