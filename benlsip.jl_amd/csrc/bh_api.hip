@@ -34,7 +34,7 @@ struct CgWorkspace {
     double *w = nullptr, *r = nullptr, *v = nullptr, *p = nullptr, *Hp = nullptr, *g = nullptr, *wl = nullptr, *wu = nullptr;
     double *x = nullptr, *s = nullptr, *xlow = nullptr, *xupp = nullptr;   // minor_iterate staging
     double* hw = nullptr;          // H*w accumulated by the CG loop for minor_iterate's linesearch
-    double *p2 = nullptr, *gpart = nullptr, *rvpart = nullptr;   // two-kernel box iteration: p ping-pong, f2b terms per chunk, r.v partials (2 x n_pad/2)
+    double *p2 = nullptr, *gpart = nullptr, *rvpart = nullptr;   // two-kernel box iteration: p ping-pong, (spare), r.v partials (2 x n_pad/2)
     double* slab = nullptr;
     double* scalars = nullptr;     // 8 doubles (linesearch alpha, ...)
     CgState* d_state = nullptr;
@@ -347,7 +347,7 @@ struct bh_hess {
     double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
     double* tbuf = nullptr;        // d + q   (t = J v between the two passes of a column-panel H*p; NULL for n <= 16384)
     double* partials = nullptr;    // g_cap x ld
-    double* sq_partials = nullptr; // g_cap
+    double* sq_partials = nullptr; // 2 x g_cap (second half: per-workgroup minima of the two-kernel CG iteration)
     double* scalar = nullptr;      // 2
     int g_cap = 0;
     int last_n_hmul = 0;           // H*p count of the previous bh_pcg on this handle (launch schedule hint)
@@ -661,7 +661,7 @@ int32_t alloc_hess_common(bh_hess* H) {
     int64_t gmax = (int64_t)g_ctx.n_cu * kMaxBlocksPerCu;
     H->g_cap = (int)gmax;
     BH_TRY(dev_alloc(&H->partials, gmax * H->ld));
-    BH_TRY(dev_alloc(&H->sq_partials, gmax));
+    BH_TRY(dev_alloc(&H->sq_partials, 2 * gmax));      // [0, gmax): sum w (Jp)^2 per workgroup; [gmax, 2 gmax): its factor_to_boundary minimum
     BH_TRY(dev_alloc(&H->scalar, 2));
     H->stats.bytes_per_hmul = (multi_panel(H) ? 16.0 : 8.0) * (double)(H->d + H->q_eff) * (double)H->n + 16.0 * (double)H->n;
     return BH_OK;
@@ -1879,7 +1879,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             f.vvec = c.v; f.p_old = pbuf[(j - 1) & 1]; f.p_new = pbuf[j & 1];
             f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nrv;
             f.w = wp; f.wl = wlp; f.wu = wup;
-            f.sqpart = H->sq_partials; f.gpart = c.gpart;
+            f.sqpart = H->sq_partials; f.gpart = H->sq_partials + H->g_cap;      // one entry per WORKGROUP (up to g_cap of them), not per chunk
             f.kappa2 = kappa2; f.atol_f2b = atol_f2b;
             f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
             int slot = -1;
@@ -1893,7 +1893,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         auto launch_update = [&](int j) {
             CgUpdArgs u{};
             u.st = c.d_state; u.j = j; u.partials = H->partials; u.ld = H->ld; u.nchunks = H->nchunks; u.G = grid;
-            u.sqpart = H->sq_partials; u.gpart = c.gpart; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nrv;
+            u.sqpart = H->sq_partials; u.gpart = H->sq_partials + H->g_cap; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nrv;
             u.p = pbuf[j & 1]; u.w = wp; u.hw = hw; u.r = c.r; u.g = gp; u.v = c.v; u.fixrank = a.fixrank;
             u.n = (int)n; u.atol_neg = atol_negcurv; u.trace = a.trace; u.trace_cap = a.trace_cap; u.mirror = a.mirror; u.tag = a.tag;
             if (peer_fused) {

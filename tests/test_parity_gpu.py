@@ -381,6 +381,33 @@ def test_pcg_wide_rows_every_kernel_geometry(bh, cg_fused, d, n, nfix, kappa2):
     H.close()
 
 
+@pytest.mark.parametrize("d,n,nfix", [(40000, 128, 9), (70000, 30, 0), (30000, 500, 40)])
+def test_pcg_tall_narrow_more_workgroups_than_columns(bh, cg_fused, d, n, nfix):
+    """Tall, narrow J: the row-streaming grid (up to 8 workgroups per CU = 2048) has MORE workgroups than the vectors have
+    entries, so every per-workgroup array of the two-kernel iteration (partial sums, minima) must be sized by the grid, not by n
+    (a buffer of n_pad doubles was overrun here once).  Against the oracle, twice (second call: launch schedule from the hint),
+    then a different subproblem on the same workspace to catch a stray write."""
+    rng = np.random.default_rng(d + n)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    fix = np.zeros(n, dtype=bool)
+    if nfix:
+        fix[rng.choice(n, nfix, replace=False)] = True
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix if nfix else None, l=-np.ones(n), u=np.ones(n))
+    Ho = R.AlHessian(J, np.zeros((0, n)), 2.0)
+    H = bh.AlHessian(J, None, 2.0)
+    cons = bh.MixedConstraints(A, None, fix)
+    for trial in range(2):
+        g = J.T @ rng.standard_normal(d) + 1e-3 * rng.standard_normal(n)
+        w_l, w_u = R.build_step_bounds(np.where(fix, 1.0, 0.0), cons_o, 0.5 * np.linalg.norm(g))
+        w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 1e-3)
+        for _ in range(2):
+            w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 1e-3, full_output=True)
+            assert int(status) == int(s_ref) and info["iters"] == it_ref, (trial, status, info["iters"], s_ref, it_ref)
+            assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 1e-3, w_ref), relnorm(w, w_ref)
+    H.close()
+
+
 def test_pcg_config5_shape_linear_constraints(bh, proj_form, cg_fused):
     """BASELINE config 5 shape at oracle-sized d: n=1024, mA=16 linear equalities + p=128 active bounds (mpp=144)."""
     d, n, mA = 2048, 1024, 16
