@@ -1,5 +1,6 @@
 // bh_api.hip — C ABI (include/benlsip_hip.h) over the gfx950 kernels of bh_kernels.hip.h.
-// One process drives one GPU; all launches go to one stream; every export is synchronous.
+// One process drives one GPU; all launches go to one stream; exports that move host data are synchronous, device-pointer
+// exports return once the host has what it is owed (option final_sync).
 #include "../../include/benlsip_hip.h"
 #include "bh_kernels.hip.h"
 
@@ -135,6 +136,12 @@ struct Ctx {
     AsyncUpload* upload_cache = nullptr;   // streams, events and staging buffers of the last finished asynchronous upload, kept for the next
     // host <-> device traffic issued by the library since bh_init (bh_stats: the device-resident entry points are checked against it)
     int64_t h2d_bytes = 0, d2h_bytes = 0, h2d_calls = 0, d2h_calls = 0;
+    // Mailbox: a host-mapped page the kernels write the few host-visible results of a device-pointer call into (counts, norms,
+    // alpha, the BitVector image), sealed by a sequence number: the host polls one word instead of paying for a DMA per
+    // scalar (~10 us each) and a hipStreamSynchronize (~10 us) per call.
+    volatile unsigned long long* mbox_h = nullptr;   // [0] = sequence number, payload from byte 64
+    unsigned long long* mbox_d = nullptr;
+    unsigned long long mbox_seq = 0;
     double* rbuf = nullptr;          // residual staging of bh_resid_sqnorm (grown on demand)
     int64_t rbuf_cap = 0;
     int live_hess = 0;               // bh_hess handles alive (a handle bakes in this rank's share of C: see bh_comm_init)
@@ -375,7 +382,7 @@ struct bh_proj {
     bool have_L = false;
     double* M = nullptr;           // mA x mA: A_free A_free' (lower triangle), kept for rank-one downdates (bh_cauchy_step)
     double* Lr = nullptr;          // mA x mA + mA: chol(M) and its reciprocal diagonal (reduced form)
-    int* info = nullptr;           // device flag of chol_lower_kernel
+    int* info = nullptr;           // device flag of the Cholesky kernels (= counts + 4)
     double* tpart = nullptr;       // (ldA/32 + 1) x mA: per-workgroup partials of A_free r (four-kernel CG iteration)
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
     bool M_valid = false;          // M = A_free A_free' for the CURRENT active set (false after factor-only downdates)
@@ -834,6 +841,15 @@ int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_dev
     return BH_OK;
 }
 
+// A device vector the kernels may read in whole 16-byte chunks up to the padded length: the caller's own buffer when it needs no
+// padding (n == n_pad) and is 16-byte aligned, else a zero-padded staging copy (pad must be zero beyond n already).
+int32_t device_operand(const double** out, double* pad, const double* v_dev, int64_t n, int64_t n_pad) {
+    if (n == n_pad && (reinterpret_cast<uintptr_t>(v_dev) & 15u) == 0) { *out = v_dev; return BH_OK; }
+    BH_TRY(stage_vec(pad, v_dev, n, true));
+    *out = pad;
+    return BH_OK;
+}
+
 // Several host vectors into CONSECUTIVE workspace vectors (stride n_pad) with one DMA instead of one each: a 32 KiB
 // hipMemcpyAsync costs ~10 us of stream time whatever its size, and the host-pointer entry points stage 3-5 of them.
 int32_t stage_vecs(double* dst_first, std::initializer_list<const double*> srcs, int64_t n, int64_t n_pad) {
@@ -885,12 +901,76 @@ int32_t sync_flush() {
     return check_peer_error();
 }
 
+// ---- mailbox ------------------------------------------------------------------------------
+constexpr size_t kMboxBytes = 64 * 1024;
+constexpr size_t kMboxPayloadOff = 64;
+constexpr size_t kMbScal = 0, kMbInts = 16, kMbChunks = 64;          // payload layout: 2 doubles | 8 ints | BitVector image
+// Optional riders: up to two doubles and `icount` ints that live in device memory (results an all-reduce or a later kernel
+// also needs there) are copied into the page by the sealing thread itself.
+__global__ void mbox_seal_kernel(unsigned long long* seq_word, unsigned long long seq, const double* a, const double* b, double* ddst,
+                                 const int* isrc, int icount, int* idst) {
+    // runs after the producers (same stream): their stores to the page were performed before they completed
+    if (a != nullptr) ddst[0] = a[0];
+    if (b != nullptr) ddst[1] = b[0];
+    for (int i = 0; i < icount; ++i) idst[i] = isrc[i];
+    __threadfence_system();
+    __hip_atomic_store(seq_word, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int32_t mbox_ensure() {
+    if (g_ctx.mbox_h) return BH_OK;
+    void* hp = nullptr;
+    BH_HIP(hipHostMalloc(&hp, kMboxBytes, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(hp, 0, kMboxBytes);
+    void* dp = nullptr;
+    BH_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+    g_ctx.mbox_h = static_cast<volatile unsigned long long*>(hp);
+    g_ctx.mbox_d = static_cast<unsigned long long*>(dp);
+    g_ctx.mbox_seq = 0;
+    return BH_OK;
+}
+// device / host views of the payload (byte offset `off`, a multiple of 8)
+template <class T> T* mbox_dev(size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(g_ctx.mbox_d) + kMboxPayloadOff + off); }
+template <class T> const volatile T* mbox_host(size_t off) {
+    return reinterpret_cast<const volatile T*>(reinterpret_cast<const volatile char*>(g_ctx.mbox_h) + kMboxPayloadOff + off);
+}
+// Seal what the kernels enqueued so far have written and wait for it.  `bytes`: payload size, for the transfer counters.
+// Pending pinned-arena traffic (host-pointer callers) or final_sync = 1: drain the stream the old way as well.
+int32_t mbox_seal_and_wait(size_t bytes, const double* a = nullptr, const double* b = nullptr, double* ddst = nullptr,
+                           const int* isrc = nullptr, int icount = 0, int* idst = nullptr) {
+    const unsigned long long seq = ++g_ctx.mbox_seq;
+    hipLaunchKernelGGL(mbox_seal_kernel, dim3(1), dim3(1), 0, g_ctx.stream, g_ctx.mbox_d, seq, a, b, ddst, isrc, icount, idst);
+    BH_HIP(hipGetLastError());
+    count_d2h(bytes);
+    if (g_ctx.opt_final_sync || pin_arena_busy()) return sync_flush();
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned long long spins = 0;
+    while (g_ctx.mbox_h[0] != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xffff) == 0) {
+            if (g_ctx.peer.active && *g_ctx.peer.h_err != 0ull) return check_peer_error();
+            const hipError_t q = hipStreamQuery(g_ctx.stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(BH_ERR_HIP, std::string("mailbox wait: ") + hipGetErrorString(q));
+            if (q == hipSuccess && g_ctx.mbox_h[0] != seq) return fail(BH_ERR_HIP, "internal: stream drained but the mailbox was not sealed");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120))
+                return fail(BH_ERR_HIP, "mailbox wait: no progress for 120 s", /*drain=*/false);
+        }
+    }
+    return check_peer_error();
+}
+// End of a device-pointer call whose results stay in HBM: nothing is owed to the host, later calls are ordered behind this
+// one on the library stream (option final_sync = 1: drain as the host-pointer entry points do).
+int32_t finish_device_call() {
+    if (g_ctx.opt_final_sync || pin_arena_busy()) return sync_flush();
+    BH_HIP(hipGetLastError());
+    return check_peer_error();
+}
+
 // ---- projection -------------------------------------------------------------------------
 int32_t ensure_reduced_buffers(bh_proj* P) {
     const int64_t mA = P->mA;
     if (!P->M) BH_TRY(dev_alloc(&P->M, mA * mA));
     if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, mA * mA + mA));
-    if (!P->info) BH_TRY(dev_alloc(&P->info, 1));
+    if (!P->info) P->info = P->counts + 4;      // (rides to the host with the AU_* counts: one copy by the mailbox's sealing thread)
     if (!P->tpart) BH_TRY(dev_alloc(&P->tpart, (P->ldA / 32 + 1) * std::max<int64_t>(mA, 1)));
     return BH_OK;
 }
@@ -1101,6 +1181,7 @@ int32_t bh_shutdown(void) {
     c = CgWorkspace();
     dev_free(g_ctx.scratch_dev); g_ctx.scratch_dev = nullptr;
     dev_free(g_ctx.rbuf); g_ctx.rbuf = nullptr; g_ctx.rbuf_cap = 0;
+    if (g_ctx.mbox_h) { (void)hipHostFree(const_cast<unsigned long long*>(g_ctx.mbox_h)); g_ctx.mbox_h = nullptr; g_ctx.mbox_d = nullptr; }
     async_upload_destroy(g_ctx.upload_cache); g_ctx.upload_cache = nullptr;
     for (auto& im : g_ctx.image_pool) dev_free(im.ptr);
     g_ctx.image_pool.clear();
@@ -1575,10 +1656,12 @@ int32_t bh_hess_shape(const bh_hess* H, int64_t* d, int64_t* n, int64_t* q) {
 static int32_t hmul_impl(bh_hess* H, const double* v, double* out, bool dev) {
     BH_REQUIRE_INIT();
     if (!H || !v || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
-    BH_TRY(stage_vec(H->vpad, v, H->n, dev));
-    BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
+    const double* vp = H->vpad;
+    if (dev) BH_TRY(device_operand(&vp, H->vpad, v, H->n, H->ld));
+    else BH_TRY(stage_vec(H->vpad, v, H->n, false));
+    BH_TRY(launch_hmul(H, vp, H->zpad, nullptr, -1));
     BH_TRY(fetch_vec(out, H->zpad, H->n, dev));
-    BH_TRY(sync_flush());
+    BH_TRY(dev ? finish_device_call() : sync_flush());
     H->stats.n_hmul += 1;
     return BH_OK;
 }
@@ -1600,14 +1683,17 @@ int32_t bh_vthv(bh_hess* H, const double* v, double* out_scalar) {
 static int32_t jv_impl(bh_hess* H, const double* v, double* out, bool dev) {
     BH_REQUIRE_INIT();
     if (!H || !v || (!out && H->d > 0)) return fail(BH_ERR_INVALID_ARG, "NULL argument");
-    BH_TRY(stage_vec(H->vpad, v, H->n, dev));
     if (dev) {
-        BH_TRY(launch_jv(H, H->vpad, out, false, nullptr));
+        const double* vp = H->vpad;
+        BH_TRY(device_operand(&vp, H->vpad, v, H->n, H->ld));
+        BH_TRY(launch_jv(H, vp, out, false, nullptr));
+        BH_TRY(finish_device_call());
     } else {
+        BH_TRY(stage_vec(H->vpad, v, H->n, false));
         BH_TRY(launch_jv(H, H->vpad, H->upad, false, nullptr));
         BH_TRY(fetch_vec(out, H->upad, H->d, false));
+        BH_TRY(sync_flush());
     }
-    BH_TRY(sync_flush());
     H->stats.n_jv += 1;
     return BH_OK;
 }
@@ -1621,7 +1707,7 @@ static int32_t jtv_impl(bh_hess* H, const double* u, double* out, bool dev) {
     if (!dev) { BH_TRY(stage_vec(H->upad, u, H->d, false)); u_dev = H->upad; }
     BH_TRY(launch_jtv(H, u_dev, H->zpad));
     BH_TRY(fetch_vec(out, H->zpad, H->n, dev));
-    BH_TRY(sync_flush());
+    BH_TRY(dev ? finish_device_call() : sync_flush());
     H->stats.n_jtv += 1;
     return BH_OK;
 }
@@ -1733,7 +1819,7 @@ int32_t bh_proj_destroy(bh_proj* P) {
     if (!P) return BH_OK;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
-    dev_free(P->Lr); dev_free(P->M); dev_free(P->info);
+    dev_free(P->Lr); dev_free(P->M);            // (P->info points into P->counts)
     dev_free(P->newidx); dev_free(P->counts); dev_free(P->chunks_dev); dev_free(P->tpart);
     delete P;
     return BH_OK;
@@ -1754,7 +1840,7 @@ static int32_t project_impl(bh_proj* P, const double* r, double* v_out, bool dev
     BH_TRY(stage_vec(P->rpad, r, P->n, dev));
     BH_TRY(launch_project(P, P->rpad, P->vtmp, nullptr));
     BH_TRY(fetch_vec(v_out, P->vtmp, P->n, dev));
-    BH_TRY(sync_flush());
+    BH_TRY(dev ? finish_device_call() : sync_flush());
     return BH_OK;
 }
 int32_t bh_project(bh_proj* P, const double* r, double* v_out) { return project_impl(P, r, v_out, false); }
@@ -2149,7 +2235,7 @@ int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const doub
 // wHw = vthv(H, w_pad) -> H->scalar (all-reduced), then alpha -> c.scalars[0]; optionally w_pad *= alpha.
 // hw: H*w accumulated by the CG loop (then w'Hw = w.hw, no sweep over J), or NULL (then wHw = vthv(H, w): one J*v pass).
 static int32_t launch_linesearch(bh_hess* H, bh_proj* P, const double* g_dev, double* w_pad, const double* wl_dev, const double* wu_dev,
-                                 bool scale_w, const double* hw = nullptr) {
+                                 bool scale_w, const double* hw = nullptr, double* alpha_dst = nullptr /* default: c.scalars[0] */) {
     CgWorkspace& c = g_ctx.cg;
     if (hw == nullptr) {
         BH_TRY(launch_jv(H, w_pad, nullptr, true, H->scalar));
@@ -2157,7 +2243,8 @@ static int32_t launch_linesearch(bh_hess* H, bh_proj* P, const double* g_dev, do
         H->stats.n_jv += 1;
     }
     hipLaunchKernelGGL(linesearch_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, g_dev, w_pad, wl_dev, wu_dev,
-                       P->nfix > 0 ? P->fixrank : (const int*)nullptr, (const double*)H->scalar, hw, (int)H->n, scale_w ? 1 : 0, c.scalars);
+                       P->nfix > 0 ? P->fixrank : (const int*)nullptr, (const double*)H->scalar, hw, (int)H->n, scale_w ? 1 : 0,
+                       alpha_dst ? alpha_dst : c.scalars);
     BH_HIP(hipGetLastError());
     return BH_OK;
 }
@@ -2207,29 +2294,41 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
     // device callers: x, s and the bounds are only read element-wise (no staging); g_minor is copied device-to-device into
     // the zero-padded workspace vector the CG kernels read in 16-byte chunks
     const double *xp = x, *sp = s_vec, *lop = xlow, *upp = xupp;
+    const double* gp = c.g;
+    double* wp = c.w;
+    // ls_from_cg: the CG loop accumulates H*w next to w, so linesearch's w'Hw (vthv(H,w), :775) costs a dot product
+    // instead of another sweep over J (-0.3 ms per minor iterate at config 3); mathematically identical, rounding ~1e-15.
+    double* hw = g_ctx.opt_ls_from_cg ? c.hw : nullptr;
     if (!dev) {
         BH_TRY(stage_vecs(c.s, {s_vec, x, xlow, xupp, g_model}, n, c.n_pad));      // c.s, c.x, c.xlow, c.xupp, c.g are consecutive
         xp = c.x; sp = c.s; lop = c.xlow; upp = c.xupp;
     } else {
-        BH_TRY(stage_vec(c.g, g_model, n, true));
+        // device callers: x, s and the bounds are only read element-wise; g_minor and w are used where they lie when the
+        // kernels' 16-byte chunk accesses stay inside them (else through the zero-padded workspace)
+        BH_TRY(device_operand(&gp, c.g, g_model, n, H->ld));
+        const bool w_ok = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(w_out) & 15u) == 0 && (hw != nullptr || n == H->ld);
+        if (w_ok) wp = w_out;
+        BH_TRY(mbox_ensure());
     }
     const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
     hipLaunchKernelGGL(step_bounds_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, xp, sp, lop, upp,
                        P->nfix > 0 ? P->fixrank : (const int*)nullptr, delta, (int)n, c.wl, c.wu);
     PcgFin fin{};
-    // ls_from_cg: the CG loop accumulates H*w next to w, so linesearch's w'Hw (vthv(H,w), :775) costs a dot product
-    // instead of another sweep over J (-0.3 ms per minor iterate at config 3); mathematically identical, rounding ~1e-15.
-    double* hw = g_ctx.opt_ls_from_cg ? c.hw : nullptr;
-    BH_TRY(pcg_run(H, P, c.g, c.wl, c.wu, c.w, true, kappa2, atol_negcurv, atol_f2b, 0, &fin, hw, !dev));
+    BH_TRY(pcg_run(H, P, gp, c.wl, c.wu, wp, wp == c.w, kappa2, atol_negcurv, atol_f2b, 0, &fin, hw, !dev));
     double alpha = std::nan("");
     const bool do_ls = fin.status != BH_CG_NEGATIVE_CURVATURE;       // :669
-    if (do_ls) {
-        BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, true, hw));
-        BH_TRY(fetch_vec(&alpha, c.scalars, 1, false));
+    if (do_ls) BH_TRY(launch_linesearch(H, P, gp, wp, c.wl, c.wu, true, hw, dev ? mbox_dev<double>(kMbScal) : nullptr));
+    if (wp == c.w) BH_TRY(fetch_vec(w_out, c.w, n, dev));
+    if (!dev) {
+        if (do_ls) BH_TRY(fetch_vec(&alpha, c.scalars, 1, false));
+        BH_TRY(sync_flush());
+    } else if (do_ls) {
+        BH_TRY(mbox_seal_and_wait(sizeof(double)));        // alpha: written by the line search straight into the mailbox
+        alpha = *mbox_host<double>(kMbScal);
+    } else {
+        BH_TRY(finish_device_call());
     }
-    BH_TRY(fetch_vec(w_out, c.w, n, dev));
-    BH_TRY(sync_flush());
-    BH_TRY(pcg_finish(H, fin));
+    BH_TRY(pcg_finish(H, fin, !dev));
     if (status) *status = fin.status;
     if (iters) *iters = fin.iter;
     if (n_hmul_out) *n_hmul_out = fin.n_hmul;
@@ -2251,7 +2350,7 @@ int32_t bh_minor_iterate_dev(bh_hess* H, bh_proj* P, const double* x_dev, const 
 }
 
 // g = Jx'*rx + Cx'*y_bar — src/basic_tralcnlss.jl:45,:74 (r = this rank's d rows; C'y_bar added by rank 0; all-reduced).
-static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info_out);
+static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info_out, int* counts_out = nullptr);
 
 static int32_t grad_impl(bh_hess* H, const double* r, const double* ybar, double* g_out, bool dev) {
     BH_REQUIRE_INIT();
@@ -2260,7 +2359,7 @@ static int32_t grad_impl(bh_hess* H, const double* r, const double* ybar, double
     BH_TRY(stage_vec(H->upad + H->d, ybar, H->q, false));         // q multipliers: always a (tiny) host vector
     BH_TRY(launch_jtv(H, H->upad, H->zpad, true));
     BH_TRY(fetch_vec(g_out, H->zpad, H->n, dev));
-    BH_TRY(sync_flush());
+    BH_TRY(sync_flush());          // (ybar is a host vector in both forms: the pinned arena has traffic in flight)
     H->stats.n_jtv += 1;
     return BH_OK;
 }
@@ -2298,8 +2397,10 @@ static int32_t hmul_add_impl(bh_hess* H, const double* s_vec, const double* g, d
     const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
     if (w_add != nullptr)      // s .+= w (:436) on the caller's device vector, then H*s + g
         hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)s_inout, w_add, s_inout, (int)n);
-    BH_TRY(stage_vec(H->vpad, s_vec, n, dev));
-    BH_TRY(launch_hmul(H, H->vpad, H->zpad, nullptr, -1));
+    const double* sp = H->vpad;
+    if (dev) BH_TRY(device_operand(&sp, H->vpad, s_vec, n, H->ld));
+    else BH_TRY(stage_vec(H->vpad, s_vec, n, false));
+    BH_TRY(launch_hmul(H, sp, H->zpad, nullptr, -1));
     if (dev) {
         hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, g, out_n, (int)n);
         BH_HIP(hipGetLastError());
@@ -2309,7 +2410,7 @@ static int32_t hmul_add_impl(bh_hess* H, const double* s_vec, const double* g, d
         hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)H->zpad, (const double*)c.g, H->zpad, (int)n);
         BH_TRY(fetch_vec(out_n, H->zpad, n, false));
     }
-    BH_TRY(sync_flush());
+    BH_TRY(dev ? finish_device_call() : sync_flush());
     H->stats.n_hmul += 1;
     return BH_OK;
 }
@@ -2347,10 +2448,12 @@ int32_t bh_proj_update_active_dev(bh_proj* P, const double* x_dev, const double*
                        mA, P->fixrank, P->newidx, P->counts);
     BH_HIP(hipGetLastError());
     int counts[4] = {0, 0, 0, 0};
-    count_d2h(sizeof(counts));
-    BH_HIP(hipMemcpyAsync(counts, P->counts, sizeof(counts), hipMemcpyDeviceToHost, s));
-    BH_TRY(sync_flush());
     if (mA > 0) {
+        // with linear equalities the host chooses between a Gram downdate and a rebuild: it needs the counts now (mailbox round
+        // trip); box constraints need nothing between the two kernels, their counts come back with the mask below
+        BH_TRY(mbox_ensure());
+        BH_TRY(mbox_seal_and_wait(sizeof(counts), nullptr, nullptr, nullptr, P->counts, 4, mbox_dev<int>(kMbInts)));
+        for (int i = 0; i < 4; ++i) counts[i] = mbox_host<int>(kMbInts)[i];
         if (counts[AU_BRANCH] == 0 && had_factor) {
             if (counts[AU_NEW] > 0) {
                 hipLaunchKernelGGL(gram_downdate_list_kernel, dim3(std::max(1, std::min(1024, (mA * mA + 255) / 256))), dim3(256), 0, s, P->M,
@@ -2363,11 +2466,13 @@ int32_t bh_proj_update_active_dev(bh_proj* P, const double* x_dev, const double*
     }
     P->active_set = false;
     int info_host = 0;
-    BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host));
+    int counts_now[4] = {0, 0, 0, 0};
+    BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host, counts_now));   // (canon_mask_kernel leaves AU_AT_BOUND / AU_BRANCH untouched)
     if (info_host != 0) {
         P->active_set = false;
         return fail(BH_ERR_PRECONDITION, "A_free*A_free' is not positive definite (PosDefException in the reference's cholesky)");
     }
+    if (mA == 0) for (int i = 0; i < 4; ++i) counts[i] = counts_now[i];                  // arrived with the mask
     if (n_at_bound) *n_at_bound = counts[AU_AT_BOUND];
     if (n_fixed) *n_fixed = P->nfix;
     if (branch) *branch = counts[AU_BRANCH];
@@ -2381,12 +2486,25 @@ int32_t bh_reduced_gradient_norm_dev(bh_proj* P, const double* g_dev, double* ou
     BH_REQUIRE_INIT();
     BH_TRY(check_proj_ready(P));
     if (!g_dev || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
-    BH_TRY(stage_vec(P->rpad, g_dev, P->n, true));
-    BH_TRY(launch_project(P, P->rpad, P->vtmp, nullptr));
-    hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, (const double*)P->vtmp, (int)P->n, P->tw);
+    BH_TRY(mbox_ensure());
+    double* res = mbox_dev<double>(kMbScal);
+    if (P->mA == 0) {
+        // box constraints: projection = mask, fused with the norm (one launch, the caller's vector read in place)
+        hipLaunchKernelGGL(vec_norm_masked_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, g_dev, P->nfix > 0 ? (const int*)P->fixrank : (const int*)nullptr,
+                           (int)P->n, res);
+    } else {
+        // a vector that needs no padding (n a multiple of 16, 16-byte aligned) is projected where it lies
+        const double* rp = g_dev;
+        if (P->n != P->ldA || (reinterpret_cast<uintptr_t>(g_dev) & 15u) != 0) {
+            BH_TRY(stage_vec(P->rpad, g_dev, P->n, true));
+            rp = P->rpad;
+        }
+        BH_TRY(launch_project(P, rp, P->vtmp, nullptr));
+        hipLaunchKernelGGL(vec_norm_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, (const double*)P->vtmp, (int)P->n, res);
+    }
     BH_HIP(hipGetLastError());
-    BH_TRY(fetch_vec(out, P->tw, 1, false));
-    BH_TRY(sync_flush());
+    BH_TRY(mbox_seal_and_wait(sizeof(double)));
+    *out = *mbox_host<double>(kMbScal);
     return BH_OK;
 }
 
@@ -2396,17 +2514,18 @@ int32_t bh_model_reduction_dev(bh_hess* H, const double* g_dev, const double* s_
     if (!H || !g_dev || !s_dev || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
     BH_TRY(ensure_cg_workspace(H->ld, 0));
     CgWorkspace& c = g_ctx.cg;
-    BH_TRY(stage_vec(H->vpad, s_dev, H->n, true));
-    BH_TRY(launch_jv(H, H->vpad, nullptr, true, H->scalar));
+    const double* sp = H->vpad;
+    BH_TRY(device_operand(&sp, H->vpad, s_dev, H->n, H->ld));
+    BH_TRY(launch_jv(H, sp, nullptr, true, H->scalar));
     BH_TRY(allreduce_inplace(H->scalar, 1, H));
     hipLaunchKernelGGL(vec_dot_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, g_dev, s_dev, (int)H->n, c.scalars + 1);
     BH_HIP(hipGetLastError());
-    double vals[2] = {0.0, 0.0};
-    BH_TRY(fetch_vec(&vals[0], H->scalar, 1, false));
-    BH_TRY(fetch_vec(&vals[1], c.scalars + 1, 1, false));
-    BH_TRY(sync_flush());
+    BH_TRY(mbox_ensure());
+    // s'Hs (all-reduced, so it lives in device memory) and g's ride to the host with the seal
+    BH_TRY(mbox_seal_and_wait(2 * sizeof(double), H->scalar, c.scalars + 1, mbox_dev<double>(kMbScal)));
+    const double vthv = mbox_host<double>(kMbScal)[0], gs = mbox_host<double>(kMbScal)[1];
     H->stats.n_jv += 1;
-    *out = vals[1] + 0.5 * vals[0];
+    *out = gs + 0.5 * vthv;
     return BH_OK;
 }
 
@@ -2414,24 +2533,37 @@ int32_t bh_model_reduction_dev(bh_hess* H, const double* g_dev, const double* s_
 // bring the canonical device arrays (fixrank = rank among the fixed, fixidx) and the host bookkeeping in line with it
 // WITHOUT moving the mask through the host: a scan kernel renumbers in place, and only the count, the BitVector image
 // (n/8 bytes: what the caller's lincons.fixvars needs) and the factorisation flag come back.
-static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info_out) {
+static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info_out, int* counts_out) {
     const int64_t n = P->n;
     const size_t nwords = (size_t)((n + 63) / 64);
-    hipLaunchKernelGGL(canon_mask_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->fixrank, P->fixidx, (int)n, (int)P->ldA, P->chunks_dev, P->counts);
-    BH_HIP(hipGetLastError());
+    BH_TRY(mbox_ensure());
+    const bool via_mbox = kMbChunks + nwords * sizeof(uint64_t) <= kMboxBytes - kMboxPayloadOff;
     std::vector<uint64_t> chunks(nwords, 0ull);
-    int counts[4] = {0, 0, 0, 0};
-    int info_host = 0;
-    count_d2h(nwords * sizeof(uint64_t) + sizeof(counts) + sizeof(int));
-    BH_HIP(hipMemcpyAsync(chunks.data(), P->chunks_dev, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost, g_ctx.stream));
-    BH_HIP(hipMemcpyAsync(counts, P->counts, sizeof(counts), hipMemcpyDeviceToHost, g_ctx.stream));
-    if (P->mA > 0 && P->info) BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
-    BH_TRY(sync_flush());
+    int counts[5] = {0, 0, 0, 0, 0};          // AU_* and, for mA > 0, the factorisation flag (P->info = P->counts + 4)
+    const bool with_info = P->mA > 0 && P->info != nullptr;
+    if (via_mbox) {
+        // the scan kernel writes the BitVector image straight into the mailbox; counts + flag ride with the seal
+        hipLaunchKernelGGL(canon_mask_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->fixrank, P->fixidx, (int)n, (int)P->ldA,
+                           mbox_dev<unsigned long long>(kMbChunks), P->counts);
+        BH_HIP(hipGetLastError());
+        BH_TRY(mbox_seal_and_wait(nwords * sizeof(uint64_t) + sizeof(counts), nullptr, nullptr, nullptr, P->counts, with_info ? 5 : 4,
+                                  mbox_dev<int>(kMbInts)));
+        for (size_t i = 0; i < nwords; ++i) chunks[i] = mbox_host<unsigned long long>(kMbChunks)[i];
+        for (int i = 0; i < (with_info ? 5 : 4); ++i) counts[i] = mbox_host<int>(kMbInts)[i];
+    } else {
+        hipLaunchKernelGGL(canon_mask_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->fixrank, P->fixidx, (int)n, (int)P->ldA, P->chunks_dev, P->counts);
+        BH_HIP(hipGetLastError());
+        count_d2h(nwords * sizeof(uint64_t) + sizeof(counts));
+        BH_HIP(hipMemcpyAsync(chunks.data(), P->chunks_dev, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost, g_ctx.stream));
+        BH_HIP(hipMemcpyAsync(counts, P->counts, (with_info ? 5 : 4) * sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+        BH_TRY(sync_flush());
+    }
     P->nfix = counts[AU_FIXED]; P->mpp = (int)P->mA + P->nfix; P->reduced = P->mA > 0; P->have_L = false;
     P->last_chunks = chunks;
     P->active_set = true;
     if (fix_chunks_out) memcpy(fix_chunks_out, chunks.data(), nwords * sizeof(uint64_t));
-    if (info_out) *info_out = info_host;
+    if (info_out) *info_out = with_info ? counts[4] : 0;
+    if (counts_out) for (int i = 0; i < 4; ++i) counts_out[i] = counts[i];
     return BH_OK;
 }
 

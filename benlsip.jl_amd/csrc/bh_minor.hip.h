@@ -122,7 +122,7 @@ __global__ __launch_bounds__(CG_T) void canon_mask_kernel(int* __restrict__ fixr
 __global__ __launch_bounds__(256) void gram_downdate_list_kernel(double* __restrict__ M, const double* __restrict__ A, int64_t ldA, int mA,
                                                                  const int* __restrict__ newidx, const int* __restrict__ counts) {
     const int n_new = counts[AU_NEW];
-    if (n_new <= 0) return;
+    if (n_new <= 0 || counts[AU_BRANCH] != 0) return;
     const int64_t total = (int64_t)mA * mA;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int i = (int)(e % mA), k = (int)(e / mA);
@@ -141,6 +141,20 @@ __global__ __launch_bounds__(CG_T) void vec_norm_kernel(const double* __restrict
     __shared__ double scratch[CG_T / 64];
     double acc[1] = {0.0};
     for (int i = threadIdx.x; i < n; i += CG_T) acc[0] = fma(v[i], v[i], acc[0]);
+    block_reduce<CG_T, 1>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) out[0] = sqrt(acc[0]);
+}
+
+// out[0] = ||mask(v)||_2: the box-constrained projection (fixed components zero) and the norm in one launch.  Same loop and
+// reduction as vec_norm_kernel over the masked vector (a masked entry contributes fma(0, 0, acc) = acc): identical bits.
+__global__ __launch_bounds__(CG_T) void vec_norm_masked_kernel(const double* __restrict__ v, const int* __restrict__ fixrank, int n,
+                                                               double* __restrict__ out) {
+    __shared__ double scratch[CG_T / 64];
+    double acc[1] = {0.0};
+    for (int i = threadIdx.x; i < n; i += CG_T) {
+        const double vi = (fixrank != nullptr && fixrank[i] >= 0) ? 0.0 : v[i];
+        acc[0] = fma(vi, vi, acc[0]);
+    }
     block_reduce<CG_T, 1>(acc, scratch, OpSum(), 0.0);
     if (threadIdx.x == 0) out[0] = sqrt(acc[0]);
 }

@@ -18,10 +18,14 @@
  *     leading dimension; indices are 0-based on the C side.
  *   - the only arithmetic type is IEEE fp64.
  *   - one process drives one GPU; handles are not thread-safe (the reference is
- *     single-threaded); every export is synchronous unless its name ends _async.
+ *     single-threaded); every export that takes or returns HOST data is
+ *     synchronous unless its name ends _async.
  *   - functions with the suffix _dev take DEVICE pointers (vectors already
  *     resident in HBM; used by bench.py and by callers that keep s, g, w on the
- *     device between calls).
+ *     device between calls).  Their device-side results are ordered on the
+ *     library stream: they return once the host has what it is owed (status
+ *     words, scalars), not necessarily after the stream has drained — see the
+ *     option "final_sync" (1 restores a full drain per call).
  *   - multi-GPU: rows of J are sharded over ranks (one process per GPU); each
  *     rank passes its own row block to bh_hess_create*.  After bh_comm_init every
  *     J'·(…) product ends in ONE RCCL all-reduce of n doubles.
@@ -292,11 +296,21 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "cg_fused"       [1] box constraints on one rank: two kernels per CG iteration (the H*p launch forms p and takes the exit test,
  *                        one kernel reduces the slabs and updates w, r, v) instead of three (H*p, slab reduction, step kernel);
  *                        2: also linear equalities (reduced form, mA <= 64): four kernels instead of seven; 0: the round-1 shapes
- *   "final_sync"     [0] bh_pcg_dev: 1 = always drain the stream before returning.  0 = return as soon as the results are final:
- *                        when the caller's device vectors are used in place and the loop was stopped by its exit test (solved /
- *                        iterations exhausted), w was complete before the launch that reported the stop began, and only
- *                        prologue-only launches that write nothing are still in flight (saves ~10 us per call); every other case
- *                        drains as before.
+ *   "final_sync"     [0] device-pointer entry points (*_dev): 1 = always drain the library stream before returning, as the
+ *                        host-pointer entry points do.  0 = return as soon as everything the HOST is owed has arrived; results
+ *                        that stay in HBM are ordered on the library stream (later calls see them; bh_synchronize, or sharing
+ *                        the caller's stream through bh_set_stream, orders them for anybody else):
+ *                        - bh_pcg_dev: when the caller's device vectors are used in place and the loop was stopped by its exit
+ *                          test (solved / iterations exhausted), w was complete before the launch that reported the stop began,
+ *                          and only prologue-only launches that write nothing are still in flight (saves ~10 us per call);
+ *                        - bh_minor_iterate_dev, bh_reduced_gradient_norm_dev, bh_model_reduction_dev, bh_proj_update_active_dev,
+ *                          bh_cauchy_step_dev: counts, norms, alpha and the BitVector image come back through a host-mapped
+ *                          mailbox page the kernels write and seal with a sequence number (no DMA per scalar, no stream
+ *                          synchronize: 84 -> 28 us for bh_proj_update_active_dev, 25 -> 11 us for a reduced-gradient norm);
+ *                        - bh_hmul_dev, bh_hmul_add_dev, bh_step_accumulate_dev, bh_jv_dev, bh_jtv_dev, bh_project_dev owe the
+ *                          host nothing and return once their work is enqueued.
+ *                        A caller's device vector is read where it lies when it needs no padding (n a multiple of 16, 16-byte
+ *                        aligned); every other case, and every host-pointer entry point, behaves as before.
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2), faster, errors accumulate)

@@ -986,8 +986,17 @@ def test_asynchronous_jacobian_ingest(bh, d, n, q, chunk_mb):
         bh.set_option("upload_chunk_mb", 64)
 
 
+@pytest.fixture(params=[0, 1], ids=["mailbox", "drained"])
+def final_sync(request, bh):
+    """Device-pointer entry points hand their few host-visible results over through the host-mapped mailbox and return without
+    draining the stream (final_sync = 0, default), or drain it the way the host-pointer entry points do (1)."""
+    bh.set_option("final_sync", request.param)
+    yield request.param
+    bh.set_option("final_sync", 0)
+
+
 @pytest.mark.parametrize("d,n,mA", [(4096, 512, 0), (1500, 300, 4)])
-def test_inner_step_device_chain_against_oracle(bh, capsys, d, n, mA):
+def test_inner_step_device_chain_against_oracle(bh, capsys, final_sync, d, n, mA):
     """One whole `inner_step` (src/basic_tralcnlss.jl:394-460: Cauchy search, then minor iterates) against the all-CPU
     oracle, (a) with every hot-path and "next"-row call on the device but host vectors in between (bh_cauchy_step,
     bh_minor_iterate, bh_hmul_add, bh_project, bh_vthv) and (b) DEVICE-RESIDENT: the library-side chain bh.inner_step, where
@@ -1038,7 +1047,7 @@ def test_inner_step_device_chain_against_oracle(bh, capsys, d, n, mA):
 
 
 @pytest.mark.parametrize("d,n,q,mA,nfix,seed", [(60, 24, 1, 0, 5, 1), (200, 65, 0, 3, 9, 2), (900, 512, 2, 8, 60, 3)])
-def test_device_pointer_entry_points_match_the_oracle(bh, d, n, q, mA, nfix, seed):
+def test_device_pointer_entry_points_match_the_oracle(bh, final_sync, d, n, q, mA, nfix, seed):
     """Every *_dev caller-level entry point on its own (bh_grad_dev, bh_hmul_add_dev, bh_step_accumulate_dev, bh_linesearch_dev,
     bh_minor_iterate_dev, bh_reduced_gradient_norm_dev, bh_model_reduction_dev, bh_cauchy_step_dev) against the oracle's
     function it replaces (src/basic_tralcnlss.jl:45, :412, :436-437, :766-791, :649-675, :869-875, :458, :574-639), with the transfer
@@ -1124,7 +1133,7 @@ def test_device_pointer_entry_points_match_the_oracle(bh, d, n, q, mA, nfix, see
 
 
 @pytest.mark.parametrize("n,mA,seed", [(40, 0, 1), (200, 5, 2), (700, 64, 3), (300, 100, 4)])
-def test_device_side_active_set_update_matches_oracle(bh, n, mA, seed):
+def test_device_side_active_set_update_matches_oracle(bh, final_sync, n, mA, seed):
     """bh_proj_update_active_dev against the reference's active_bounds + add_active! / active_bounds!
     (src/polyhedral_constraints.jl:203-261; src/basic_tralcnlss.jl:439-453): same |active_indx|, same branch, same fixvars, and
     the projector of the updated set (factor obtained by a Gram DOWNDATE over the newly fixed columns) agrees with the
