@@ -106,7 +106,10 @@ struct Ctx {
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
-    int64_t opt_final_sync = 0;      // bh_pcg_dev: always drain the stream before returning (1), or only when results may still be in flight (0)
+    int64_t opt_final_sync = 0;      // *_dev: always drain the stream before returning (1), or only wait for what the host is owed (0)
+    // the end-of-call wait of the host-pointer entry points: hipStreamSynchronize (0) or a mailbox seal + poll (1: A/B'd, SLOWER —
+    // a kernel behind a D2H DMA pays a cross-engine dependency: bh_pcg 0.667 -> 0.72 ms, bh_project 34 -> 45-50 us; kept as a switch)
+    int64_t opt_mbox_flush = 0;
     int64_t opt_cg_fused = 1;        // box CG: two kernels per iteration (H*p with the p-update folded in + reduce/update) instead of three
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
     int64_t opt_upload_chunk_mb = 64; // bh_hess_create_async: MiB of J per pipelined column chunk
@@ -890,17 +893,6 @@ int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_dev
     return BH_OK;
 }
 
-// hipStreamSynchronize + deliver the results parked in the pinned arena + reset the arena.
-int32_t sync_flush() {
-    hipError_t e = hipStreamSynchronize(g_ctx.stream);
-    if (e == hipSuccess)
-        for (const PendingOut& o : g_pin.outs) memcpy(o.dst, o.pin, (size_t)o.n * sizeof(double));
-    g_pin.outs.clear();
-    g_pin.used = 0;
-    if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
-    return check_peer_error();
-}
-
 // ---- mailbox ------------------------------------------------------------------------------
 constexpr size_t kMboxBytes = 64 * 1024;
 constexpr size_t kMboxPayloadOff = 64;
@@ -933,15 +925,18 @@ template <class T> T* mbox_dev(size_t off) { return reinterpret_cast<T*>(reinter
 template <class T> const volatile T* mbox_host(size_t off) {
     return reinterpret_cast<const volatile T*>(reinterpret_cast<const volatile char*>(g_ctx.mbox_h) + kMboxPayloadOff + off);
 }
-// Seal what the kernels enqueued so far have written and wait for it.  `bytes`: payload size, for the transfer counters.
-// Pending pinned-arena traffic (host-pointer callers) or final_sync = 1: drain the stream the old way as well.
-int32_t mbox_seal_and_wait(size_t bytes, const double* a = nullptr, const double* b = nullptr, double* ddst = nullptr,
-                           const int* isrc = nullptr, int icount = 0, int* idst = nullptr) {
+// Enqueue the seal; returns its sequence number through *seq_out.
+int32_t mbox_seal(unsigned long long* seq_out, const double* a = nullptr, const double* b = nullptr, double* ddst = nullptr,
+                  const int* isrc = nullptr, int icount = 0, int* idst = nullptr) {
     const unsigned long long seq = ++g_ctx.mbox_seq;
     hipLaunchKernelGGL(mbox_seal_kernel, dim3(1), dim3(1), 0, g_ctx.stream, g_ctx.mbox_d, seq, a, b, ddst, isrc, icount, idst);
     BH_HIP(hipGetLastError());
-    count_d2h(bytes);
-    if (g_ctx.opt_final_sync || pin_arena_busy()) return sync_flush();
+    *seq_out = seq;
+    return BH_OK;
+}
+// Spin until the seal `seq` has been observed: the stream executes in order, so EVERYTHING enqueued before the seal — kernels,
+// DMAs into and out of the pinned arena — has completed by then.
+int32_t mbox_poll(unsigned long long seq) {
     const auto t0 = std::chrono::steady_clock::now();
     unsigned long long spins = 0;
     while (g_ctx.mbox_h[0] != seq) {
@@ -955,6 +950,48 @@ int32_t mbox_seal_and_wait(size_t bytes, const double* a = nullptr, const double
                 return fail(BH_ERR_HIP, "mailbox wait: no progress for 120 s", /*drain=*/false);
         }
     }
+    return BH_OK;
+}
+void pin_arena_deliver() {
+    for (const PendingOut& o : g_pin.outs) memcpy(o.dst, o.pin, (size_t)o.n * sizeof(double));
+    g_pin.outs.clear();
+    g_pin.used = 0;
+}
+
+// Wait until everything enqueued has completed, deliver the results parked in the pinned arena, reset the arena:
+// hipStreamSynchronize.  (Experiment switch mailbox_flush = 1: a seal in the mailbox + a poll instead.  It pays where no DMA
+// precedes it — the device-pointer entry points use it through mbox_seal_and_wait — but behind a D2H DMA the seal kernel
+// waits for a cross-engine dependency that costs more than the synchronize it replaces: measured slower, off by default.)
+int32_t sync_flush() {
+    if (!g_ctx.opt_final_sync && g_ctx.opt_mbox_flush && g_ctx.mbox_h != nullptr) {
+        unsigned long long seq = 0;
+        BH_TRY(mbox_seal(&seq));
+        BH_TRY(mbox_poll(seq));
+        pin_arena_deliver();
+        return check_peer_error();
+    }
+    hipError_t e = hipStreamSynchronize(g_ctx.stream);
+    if (e == hipSuccess) pin_arena_deliver();
+    g_pin.outs.clear();
+    g_pin.used = 0;
+    if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return check_peer_error();
+}
+
+// Seal what the kernels enqueued so far have written into the mailbox (plus the riders) and wait for it.  `bytes`: payload
+// size, for the transfer counters.  Results parked in the pinned arena by a host-pointer caller are delivered as well.
+int32_t mbox_seal_and_wait(size_t bytes, const double* a = nullptr, const double* b = nullptr, double* ddst = nullptr,
+                           const int* isrc = nullptr, int icount = 0, int* idst = nullptr) {
+    unsigned long long seq = 0;
+    BH_TRY(mbox_seal(&seq, a, b, ddst, isrc, icount, idst));
+    count_d2h(bytes);
+    if (g_ctx.opt_final_sync) {
+        const hipError_t e = hipStreamSynchronize(g_ctx.stream);
+        if (e != hipSuccess) return fail(BH_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    } else {
+        BH_TRY(mbox_poll(seq));
+    }
+    pin_arena_deliver();
     return check_peer_error();
 }
 // End of a device-pointer call whose results stay in HBM: nothing is owed to the host, later calls are ordered behind this
@@ -1156,6 +1193,8 @@ int32_t bh_init(int32_t device, int32_t flags) {
     BH_HIP(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
     g_ctx.stream = g_ctx.own_stream;
     BH_TRY(dev_alloc(&g_ctx.scratch_dev, 1024));
+    BH_TRY(mbox_ensure());
+    if (const char* s = getenv("BH_MAILBOX_FLUSH")) g_ctx.opt_mbox_flush = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_RS_VARIANT")) g_ctx.opt_variant = atoll(s);
     if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = std::min<int64_t>(std::max<int64_t>(0, atoll(s)), kMaxBlocksPerCu);
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(0, atoll(s));
@@ -1234,6 +1273,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
         return BH_OK;
     }
     if (!strcmp(key, "final_sync")) { g_ctx.opt_final_sync = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "mailbox_flush")) { g_ctx.opt_mbox_flush = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
@@ -2302,6 +2342,7 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
     if (!dev) {
         BH_TRY(stage_vecs(c.s, {s_vec, x, xlow, xupp, g_model}, n, c.n_pad));      // c.s, c.x, c.xlow, c.xupp, c.g are consecutive
         xp = c.x; sp = c.s; lop = c.xlow; upp = c.xupp;
+        BH_TRY(mbox_ensure());
     } else {
         // device callers: x, s and the bounds are only read element-wise; g_minor and w are used where they lie when the
         // kernels' 16-byte chunk accesses stay inside them (else through the zero-padded workspace)
@@ -2317,11 +2358,12 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
     BH_TRY(pcg_run(H, P, gp, c.wl, c.wu, wp, wp == c.w, kappa2, atol_negcurv, atol_f2b, 0, &fin, hw, !dev));
     double alpha = std::nan("");
     const bool do_ls = fin.status != BH_CG_NEGATIVE_CURVATURE;       // :669
-    if (do_ls) BH_TRY(launch_linesearch(H, P, gp, wp, c.wl, c.wu, true, hw, dev ? mbox_dev<double>(kMbScal) : nullptr));
+    // alpha is written by the line search straight into the host-mapped mailbox (no DMA of its own)
+    if (do_ls) BH_TRY(launch_linesearch(H, P, gp, wp, c.wl, c.wu, true, hw, mbox_dev<double>(kMbScal)));
     if (wp == c.w) BH_TRY(fetch_vec(w_out, c.w, n, dev));
     if (!dev) {
-        if (do_ls) BH_TRY(fetch_vec(&alpha, c.scalars, 1, false));
-        BH_TRY(sync_flush());
+        BH_TRY(sync_flush());                               // w comes back through the pinned arena: the stream is drained
+        if (do_ls) { count_d2h(sizeof(double)); alpha = *mbox_host<double>(kMbScal); }
     } else if (do_ls) {
         BH_TRY(mbox_seal_and_wait(sizeof(double)));        // alpha: written by the line search straight into the mailbox
         alpha = *mbox_host<double>(kMbScal);
