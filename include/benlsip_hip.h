@@ -311,6 +311,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *                          host nothing and return once their work is enqueued.
  *                        A caller's device vector is read where it lies when it needs no padding (n a multiple of 16, 16-byte
  *                        aligned); every other case, and every host-pointer entry point, behaves as before.
+ *   "mailbox_flush"  [0] experiment: end the host-pointer entry points with a mailbox seal + poll instead of
+ *                        hipStreamSynchronize (measured slower behind a D2H DMA)
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2), faster, errors accumulate)
