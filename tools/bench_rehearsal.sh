@@ -2,8 +2,8 @@
 # GPU box (one GPU): rehearse bench.py's N > 1 flow — all ranks on device 0, gloo for torch.  Not a measurement.
 #   1. N = 2 weak and N = 3 strong scaling over the library's peer-buffer transport (hipIpc between processes on one device);
 #   2. N = 2 with BH_COMM=both — the configuration bench.py picks on a real multi-GPU node: the RCCL call site is bound to the
-#      host-staged stand-in (RCCL itself refuses duplicate devices), the peer-buffer transport comes up next to it, the headline
-#      is timed on the "RCCL" path and the comm section switches paths, times both all-reduces and re-runs on the peer path.
+#      host-staged stand-in (RCCL itself refuses duplicate devices), the peer-buffer transport comes up next to it, the K timed
+#      steps run on each, the valid and faster run becomes the headline, and the comm section times both all-reduces.
 R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out
