@@ -122,6 +122,12 @@ class ShardedHipOps(HipOpsDeviceAll):
             H.close()
 
 
+class ShardedResidentOps(ShardedHipOps, HipOpsResident):
+    """Row-sharded AND device-resident: the library's inner_step chain (HipOpsResident) with the communicator up — its Cauchy
+    search, minor iterates, H*s+g and model reduction all-reduce inside the device-pointer entry points, whose scalars come back
+    through the mailbox on every rank."""
+
+
 class ShadowOps:
     """Runs the device backend AND the oracle on identical inputs at every hot-path call and carries the DEVICE result
     forward.  A divergence of two free-running solves says nothing about where it started; here every call is compared on

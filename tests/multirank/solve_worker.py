@@ -33,7 +33,8 @@ def main():
     rank, world, workdir, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     import benlsip_jl_amd as bh
     import benlsip_ref as R                      # the restated DRIVER only; every numerical kernel call goes to the library
-    from hip_ops import ShardedHipOps
+    from hip_ops import ShardedHipOps, ShardedResidentOps
+    resident = len(sys.argv) > 5 and sys.argv[5] == "resident"
     bh.init(0)
     idfile = os.path.join(workdir, "unique_id_%s.bin" % name)
 
@@ -53,7 +54,7 @@ def main():
     bh.init_distributed(rank, world, bcast)
     P = problem(name)
     lo, hi = bh.row_shard(P["d"], rank, world)
-    ops = ShardedHipOps(bh)
+    ops = ShardedResidentOps(bh) if resident else ShardedHipOps(bh)
     log = []
     t0 = time.perf_counter()
     x, y = R.tralcnllss(P["x0"], lambda z: P["r"](z)[lo:hi], lambda z: P["jac_r"](z)[lo:hi], P["c"], P["jac_c"], P["A"], P["b"],

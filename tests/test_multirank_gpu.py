@@ -137,8 +137,9 @@ def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     assert int(z["n_allreduce"]) >= int(z["box_tight_nh"]) + int(z["cauchy_nh"])
 
 
-@pytest.mark.parametrize("name,world", [("sphere", 2), ("sphere", 3), ("nls48", 2), ("nls48", 3)])
-def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name, world):
+@pytest.mark.parametrize("name,world,chain", [("sphere", 2, "host"), ("sphere", 3, "host"), ("nls48", 2, "host"), ("nls48", 3, "host"),
+                                              ("sphere", 2, "resident"), ("nls48", 2, "resident")])
+def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name, world, chain):
     """the documented multi-GPU flow end to end.  The restated outer iteration runs replicated in `world`
     processes whose residual / Jacobian callbacks return only their own rows; mx, g and the least-squares multipliers come from
     the all-reduced entry points (bh_resid_sqnorm, bh_grad, bh_jtv), every hot-path call from the library, the exchange over
@@ -147,7 +148,8 @@ def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name
     identical up to the first decision whose deciding scalar is rounding noise in the reference's own arithmetic
     (rho = ared/pred with |ared| worth a few ulps of mx, src/basic_tralcnlss.jl:353-354), and the solutions must agree."""
     import solve_worker
-    run_ranks("solve_worker.py", world, tmp_path, "ipc", extra=[name])
+    # chain = "resident": the whole inner step on the library's device-resident chain (bh.inner_step) under row sharding
+    run_ranks("solve_worker.py", world, tmp_path, "ipc", extra=[name] + (["resident"] if chain == "resident" else []))
     xs = [np.load(os.path.join(tmp_path, "solve_%s_rank%d.npz" % (name, r))) for r in range(world)]
     js = [json.load(open(os.path.join(tmp_path, "solve_%s_rank%d.json" % (name, r)))) for r in range(world)]
     for r in range(1, world):
@@ -160,8 +162,8 @@ def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name
     diff = first_decision_difference(log_ref, log)
     n_minor = sum(e[0] == "minor" for e in log)
     with capsys.disabled():
-        print("[sharded solve %s x%d] %d minor iterates (oracle %d), %.1f s per rank, |x - x_oracle| = %.2e, first decision difference: %s"
-              % (name, world, n_minor, sum(e[0] == "minor" for e in log_ref), js[0]["seconds"], np.linalg.norm(xs[0]["x"] - x_ref),
+        print("[sharded solve %s x%d %s] %d minor iterates (oracle %d), %.1f s per rank, |x - x_oracle| = %.2e, first decision difference: %s"
+              % (name, world, chain, n_minor, sum(e[0] == "minor" for e in log_ref), js[0]["seconds"], np.linalg.norm(xs[0]["x"] - x_ref),
                  "none" if diff is None else "log entry %d: %s" % (diff[0], diff[3])))
     if diff is None:
         assert len(log) == len(log_ref)
