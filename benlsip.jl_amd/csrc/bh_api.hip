@@ -2347,7 +2347,8 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
         // device callers: x, s and the bounds are only read element-wise; g_minor and w are used where they lie when the
         // kernels' 16-byte chunk accesses stay inside them (else through the zero-padded workspace)
         BH_TRY(device_operand(&gp, c.g, g_model, n, H->ld));
-        const bool w_ok = (n % 2 == 0) && (reinterpret_cast<uintptr_t>(w_out) & 15u) == 0 && (hw != nullptr || n == H->ld);
+        // (w: the two-kernel iteration reads and writes whole 16-byte chunks up to the padded length)
+        const bool w_ok = (n == H->ld) && (reinterpret_cast<uintptr_t>(w_out) & 15u) == 0;
         if (w_ok) wp = w_out;
         BH_TRY(mbox_ensure());
     }
