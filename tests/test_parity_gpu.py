@@ -1132,14 +1132,15 @@ def test_device_pointer_entry_points_match_the_oracle(bh, final_sync, d, n, q, m
     H.close()
 
 
-@pytest.mark.parametrize("n", [24, 30, 32, 65, 112])
-def test_device_pointer_calls_stay_inside_the_callers_buffers(bh, cg_fused, n):
+@pytest.mark.parametrize("n,mA", [(24, 0), (30, 0), (32, 0), (65, 0), (112, 0), (30, 3), (48, 5), (65, 2)])
+def test_device_pointer_calls_stay_inside_the_callers_buffers(bh, cg_fused, n, mA):
     """The device-pointer entry points use the caller's vectors where they lie when the kernels' 16-byte chunk accesses fit
     (n a multiple of 16) and through the padded workspace otherwise.  Every caller vector here is carved out of ONE device
     arena with NaN canaries between the vectors: a write past the end of a vector changes a canary, a read past the end that
-    reaches a result turns it into NaN (n = 24, 30: even but not a multiple of 16 — the case an in-place rule gets wrong first)."""
+    reaches a result turns it into NaN (n = 24, 30: even but not a multiple of 16 — the case an in-place rule gets wrong first).
+    All *_dev entry points, box constraints and linear equalities, every CG iteration shape."""
     import ctypes as ct
-    rng = np.random.default_rng(n)
+    rng = np.random.default_rng(n + 7 * mA)
     lib = bh._lib.lib()
     d = 40 * n
     J = rng.standard_normal((d, n)) / np.sqrt(d)
@@ -1147,26 +1148,30 @@ def test_device_pointer_calls_stay_inside_the_callers_buffers(bh, cg_fused, n):
     fix[rng.choice(n, n // 5, replace=False)] = True
     xl, xu = -np.ones(n), np.ones(n)
     x = np.where(fix, 1.0, 0.2 * rng.standard_normal(n))
-    A = np.zeros((0, n))
-    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix, l=xl, u=xu)
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    cons_o = R.make_mixed_constraints(A, L0, fix, l=xl, u=xu)
     Ho = R.AlHessian(J, np.zeros((0, n)), 1.5)
     H = bh.AlHessian(J, None, 1.5)
-    cons = bh.MixedConstraints(A, None, fix, l=xl, u=xu)
+    cons = bh.MixedConstraints(A, cons_o.chol_L if mA else None, fix, l=xl, u=xu)
     P = cons.handle
-    g = J.T @ rng.standard_normal(d)
+    rx = rng.standard_normal(d)
+    g = J.T @ rx
     s0 = np.zeros(n)
     delta = 0.4 * np.linalg.norm(g)
     w_l, w_u = R.build_step_bounds(x + s0, cons_o, delta)
-    names = ["x", "s", "g", "gm", "xl", "xu", "wl", "wu", "w", "w2", "t"]
+    vecs = {"x": x, "s": s0, "g": g, "gm": g, "xl": xl, "xu": xu, "wl": w_l, "wu": w_u, "w": np.zeros(n), "w2": np.zeros(n), "t": np.zeros(n),
+            "pv": np.zeros(n), "gr": np.zeros(n), "cs": np.zeros(n), "jt": np.zeros(n), "rx": rx, "u": np.zeros(d)}
     gap = 34                                           # canaries between the vectors (even: every vector stays 16-byte aligned)
-    stride = n + (n % 2) + gap
-    host = np.full(stride * len(names) + gap, np.nan)
-    off = {k: gap + i * stride for i, k in enumerate(names)}
-    for k, v in (("x", x), ("s", s0), ("g", g), ("gm", g), ("xl", xl), ("xu", xu), ("wl", w_l), ("wu", w_u), ("w", np.zeros(n)), ("w2", np.zeros(n)),
-                 ("t", np.zeros(n))):
-        host[off[k]:off[k] + n] = v
+    off, pos = {}, gap
+    for k, v in vecs.items():
+        off[k] = pos
+        pos += v.size + (v.size % 2) + gap
+    host = np.full(pos, np.nan)
+    for k, v in vecs.items():
+        host[off[k]:off[k] + v.size] = v
     arena = bh.DeviceVector(host.size, host)
-    ptr = {k: ct.c_void_p(arena.ptr.value + 8 * off[k]) for k in names}
+    ptr = {k: ct.c_void_p(arena.ptr.value + 8 * off[k]) for k in vecs}
     st, it, nh, al, out = ct.c_int32(), ct.c_int32(), ct.c_int32(), ct.c_double(), ct.c_double()
     chk = bh._lib.check
     chk(lib.bh_pcg_dev(H.handle, P, ptr["g"], ptr["wl"], ptr["wu"], 0.1, R.SQRT_EPS, 1e-10, ptr["w"], ct.byref(st), ct.byref(it), None, 0, ct.byref(nh)), "pcg_dev")
@@ -1175,25 +1180,42 @@ def test_device_pointer_calls_stay_inside_the_callers_buffers(bh, cg_fused, n):
                                  ct.byref(st), ct.byref(it), ct.byref(nh), ct.byref(al)), "minor_iterate_dev")
     w2_ref, st2_ref = R.minor_iterate(x, s0, g, Ho, cons_o, delta, 0.1)
     chk(lib.bh_hmul_dev(H.handle, ptr["g"], ptr["t"]), "hmul_dev")
+    chk(lib.bh_project_dev(P, ptr["g"], ptr["pv"]), "project_dev")
+    chk(lib.bh_jv_dev(H.handle, ptr["g"], ptr["u"]), "jv_dev")
+    chk(lib.bh_jtv_dev(H.handle, ptr["rx"], ptr["jt"]), "jtv_dev")
+    chk(lib.bh_grad_dev(H.handle, ptr["rx"], None, ptr["gr"]), "grad_dev")
+    chk(lib.bh_linesearch_dev(H.handle, P, ptr["g"], ptr["w"], ptr["wl"], ptr["wu"], ct.byref(out)), "linesearch_dev")
+    ls = out.value
     chk(lib.bh_reduced_gradient_norm_dev(P, ptr["g"], ct.byref(out)), "norm")
     nrm = out.value
     chk(lib.bh_model_reduction_dev(H.handle, ptr["g"], ptr["w2"], ct.byref(out)), "mr")
     mr = out.value
     chk(lib.bh_step_accumulate_dev(H.handle, ptr["s"], ptr["w2"], ptr["g"], ptr["gm"]), "acc")
+    mid = arena.download()
+    # the Cauchy search last: it replaces the active set of the handle
+    chunks = np.zeros((n + 63) // 64, dtype=np.uint64)
+    nbp = ct.c_int32()
+    chk(lib.bh_cauchy_step_dev(H.handle, P, ptr["x"], ptr["g"], ptr["xl"], ptr["xu"], delta, ptr["cs"], bh._lib.ptr(chunks), ct.byref(nbp), ct.byref(nh)),
+        "cauchy_step_dev")
     back = arena.download()
     mask = np.ones(host.size, dtype=bool)
-    for k in names:
-        mask[off[k]:off[k] + n] = False
+    for k, v in vecs.items():
+        mask[off[k]:off[k] + v.size] = False
     assert np.all(np.isnan(back[mask])), "a canary between the caller's vectors was overwritten: %s" % np.flatnonzero(~np.isnan(back[mask]))[:8]
-    get = lambda k: back[off[k]:off[k] + n]
-    assert np.all(np.isfinite(get("w"))) and np.all(np.isfinite(get("w2"))) and np.all(np.isfinite(get("t"))) and np.all(np.isfinite(get("gm")))
-    assert relnorm(get("w"), w_ref) <= max(1e-8, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref))
-    assert relnorm(get("w2"), w2_ref) <= max(1e-8, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref))
-    assert relnorm(get("t"), R.hmul(Ho, g)) <= 1e-12
-    assert nrm == pytest.approx(R.norm_reduced_gradient(g, cons_o), rel=1e-10)
-    assert mr == pytest.approx(float(g @ w2_ref) + 0.5 * R.vthv(Ho, w2_ref), rel=1e-6, abs=1e-12)
-    assert relnorm(get("s"), s0 + w2_ref) <= max(1e-8, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref))
-    assert relnorm(get("gm"), R.hmul(Ho, s0 + get("w2")) + g) <= 1e-10
+    get = lambda k, src=mid: src[off[k]:off[k] + vecs[k].size]
+    for k in ("w", "w2", "t", "gm", "pv", "u", "jt", "gr"):
+        assert np.all(np.isfinite(get(k))), k
+    tol = max(1e-8, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref))
+    assert relnorm(get("w"), w_ref) <= tol and relnorm(get("w2"), w2_ref) <= tol
+    assert relnorm(get("t"), R.hmul(Ho, g)) <= 1e-12 and relnorm(get("u"), J @ g) <= 1e-12 and relnorm(get("jt"), g) <= 1e-12 and relnorm(get("gr"), g) <= 1e-12
+    assert relnorm(get("pv"), R.projection(cons_o, g)) <= 1e-9
+    assert ls == pytest.approx(R.linesearch(g, Ho, get("w"), w_l, w_u, cons_o.fixvars), rel=1e-9)
+    assert nrm == pytest.approx(R.norm_reduced_gradient(g, cons_o), rel=1e-9)
+    assert mr == pytest.approx(float(g @ get("w2")) + 0.5 * R.vthv(Ho, get("w2")), rel=1e-9, abs=1e-12)
+    assert relnorm(get("s"), s0 + get("w2")) <= 1e-15 and relnorm(get("gm"), R.hmul(Ho, get("s")) + g) <= 1e-10
+    cau = R.make_mixed_constraints(A, L0, l=xl, u=xu)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cau, delta, R.NumpyOps())
+    assert np.all(np.isfinite(get("cs", back))) and relnorm(get("cs", back), s_ref) <= 1e-8
     H.close()
 
 
