@@ -110,6 +110,7 @@ struct Ctx {
     // the end-of-call wait of the host-pointer entry points: hipStreamSynchronize (0) or a mailbox seal + poll (1: A/B'd, SLOWER —
     // a kernel behind a D2H DMA pays a cross-engine dependency: bh_pcg 0.667 -> 0.72 ms, bh_project 34 -> 45-50 us; kept as a switch)
     int64_t opt_mbox_flush = 0;
+    int64_t opt_host_copy_kernels = 1;   // host vectors of the host-pointer entry points: copy kernels on the mapped pinned arena (1) or DMA (0)
     int64_t opt_cg_fused = 1;        // box CG: two kernels per iteration (H*p with the p-update folded in + reduce/update) instead of three
     int64_t opt_proj_form = 1;       // 1: reduced mA x mA form (fast), 0: the reference's augmented mpp x mpp form
     int64_t opt_upload_chunk_mb = 64; // bh_hess_create_async: MiB of J per pipelined column chunk
@@ -799,17 +800,34 @@ int32_t upload_transposed(const double* host, int64_t rows, int64_t cols, int64_
 struct PendingOut { double* dst; const double* pin; int64_t n; };
 struct PinArena {
     char* base = nullptr;
+    char* dev_base = nullptr;      // the same pages as the GPU sees them (pinned host memory is mapped into the device's address space)
     size_t cap = 0, used = 0;
     std::vector<PendingOut> outs;
+    bool dma = false;              // a DMA engine transfer has been enqueued since the last flush (then the flush must be a real drain)
 };
 PinArena g_pin;
+inline void note_dma() { g_pin.dma = true; }
+// Small host <-> device vector copies done by a KERNEL on the mapped arena instead of a DMA engine: a 32 KiB hipMemcpyAsync costs
+// ~10 us of stream time and a kernel behind it another cross-engine dependency; a copy kernel reads / writes the pinned pages
+// over PCIe in ~3 us and keeps everything on the compute queue, so that the call can end with a mailbox seal + poll instead
+// of a hipStreamSynchronize.
+__global__ __launch_bounds__(256) void arena_copy_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+inline double* pin_dev_view(const double* pin) { return reinterpret_cast<double*>(g_pin.dev_base + (reinterpret_cast<const char*>(pin) - g_pin.base)); }
+inline bool arena_kernels() { return g_ctx.opt_host_copy_kernels != 0 && g_pin.dev_base != nullptr; }
+inline void launch_arena_copy(double* dst, const double* src, int64_t n) {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 256));
+    hipLaunchKernelGGL(arena_copy_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, dst, src, n);
+}
 bool pin_arena_busy() { return g_pin.used > 0; }
 void pin_arena_abandon(bool drained) {
     g_pin.outs.clear();
     g_pin.used = 0;
     // transfers may still be in flight (the stream could not be drained): retire this arena — it is leaked on purpose,
     // a later pin_alloc maps a fresh one — rather than let the next call's vectors share memory with a stale DMA
-    if (!drained) { g_pin.base = nullptr; g_pin.cap = 0; }
+    if (!drained) { g_pin.base = nullptr; g_pin.dev_base = nullptr; g_pin.cap = 0; }
+    g_pin.dma = false;
 }
 constexpr size_t kPinArenaBytes = 32u << 20;
 constexpr int64_t kPinMaxVec = 1 << 20;     // doubles; larger transfers go directly (bandwidth-, not latency-bound)
@@ -821,6 +839,9 @@ double* pin_alloc(int64_t n) {
         if (hipHostMalloc(&p, kPinArenaBytes, hipHostMallocDefault) != hipSuccess) return nullptr;
         g_pin.base = static_cast<char*>(p);
         g_pin.cap = kPinArenaBytes;
+        void* dp = nullptr;
+        g_pin.dev_base = (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess) ? static_cast<char*>(dp) : nullptr;
+        if (g_pin.dev_base == nullptr) (void)hipGetLastError();
     }
     const size_t bytes = ((size_t)n * sizeof(double) + 255) & ~(size_t)255;
     if (g_pin.used + bytes > g_pin.cap) return nullptr;
@@ -835,9 +856,12 @@ int32_t stage_vec(double* dst_pad, const double* src, int64_t n, bool src_is_dev
     if (!src_is_device) {
         if (double* pin = pin_alloc(n)) {
             memcpy(pin, src, (size_t)n * sizeof(double));
+            if (arena_kernels()) { launch_arena_copy(dst_pad, pin_dev_view(pin), n); BH_HIP(hipGetLastError()); return BH_OK; }
+            note_dma();
             BH_HIP(hipMemcpyAsync(dst_pad, pin, (size_t)n * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
             return BH_OK;
         }
+        note_dma();
     }
     BH_HIP(hipMemcpyAsync(dst_pad, src, (size_t)n * sizeof(double), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                           g_ctx.stream));
@@ -874,6 +898,8 @@ int32_t stage_vecs(double* dst_first, std::initializer_list<const double*> srcs,
         ++i;
     }
     count_h2d((size_t)k * n * sizeof(double));
+    if (arena_kernels()) { launch_arena_copy(dst_first, pin_dev_view(pin), k * n_pad); BH_HIP(hipGetLastError()); return BH_OK; }
+    note_dma();
     BH_HIP(hipMemcpyAsync(dst_first, pin, (size_t)(k * n_pad) * sizeof(double), hipMemcpyHostToDevice, g_ctx.stream));
     return BH_OK;
 }
@@ -883,10 +909,12 @@ int32_t fetch_vec(double* dst, const double* src_dev, int64_t n, bool dst_is_dev
     if (!dst_is_device) count_d2h((size_t)n * sizeof(double));
     if (!dst_is_device) {
         if (double* pin = pin_alloc(n)) {
-            BH_HIP(hipMemcpyAsync(pin, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
+            if (arena_kernels()) { launch_arena_copy(pin_dev_view(pin), src_dev, n); BH_HIP(hipGetLastError()); }
+            else { note_dma(); BH_HIP(hipMemcpyAsync(pin, src_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream)); }
             g_pin.outs.push_back({dst, pin, n});
             return BH_OK;
         }
+        note_dma();
     }
     BH_HIP(hipMemcpyAsync(dst, src_dev, (size_t)n * sizeof(double), dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
                           g_ctx.stream));
@@ -963,7 +991,11 @@ void pin_arena_deliver() {
 // precedes it — the device-pointer entry points use it through mbox_seal_and_wait — but behind a D2H DMA the seal kernel
 // waits for a cross-engine dependency that costs more than the synchronize it replaces: measured slower, off by default.)
 int32_t sync_flush() {
-    if (!g_ctx.opt_final_sync && g_ctx.opt_mbox_flush && g_ctx.mbox_h != nullptr) {
+    // No DMA engine involved since the last flush (the host vectors travelled through arena_copy_kernel): a seal + poll ends
+    // the call without a hipStreamSynchronize.  (mailbox_flush = 1 forces the seal path also behind DMAs: measured slower.)
+    const bool kernels_only = arena_kernels() && !g_pin.dma;
+    g_pin.dma = false;
+    if (!g_ctx.opt_final_sync && (g_ctx.opt_mbox_flush || kernels_only) && g_ctx.mbox_h != nullptr) {
         unsigned long long seq = 0;
         BH_TRY(mbox_seal(&seq));
         BH_TRY(mbox_poll(seq));
@@ -1195,6 +1227,7 @@ int32_t bh_init(int32_t device, int32_t flags) {
     BH_TRY(dev_alloc(&g_ctx.scratch_dev, 1024));
     BH_TRY(mbox_ensure());
     if (const char* s = getenv("BH_MAILBOX_FLUSH")) g_ctx.opt_mbox_flush = atoll(s) ? 1 : 0;
+    if (const char* s = getenv("BH_HOST_COPY_KERNELS")) g_ctx.opt_host_copy_kernels = atoll(s) ? 1 : 0;
     if (const char* s = getenv("BH_RS_VARIANT")) g_ctx.opt_variant = atoll(s);
     if (const char* s = getenv("BH_BLOCKS_PER_CU")) g_ctx.opt_blocks_per_cu = std::min<int64_t>(std::max<int64_t>(0, atoll(s)), kMaxBlocksPerCu);
     if (const char* s = getenv("BH_PCG_BATCH")) g_ctx.opt_batch = std::max<int64_t>(0, atoll(s));
@@ -1274,6 +1307,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     }
     if (!strcmp(key, "final_sync")) { g_ctx.opt_final_sync = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "mailbox_flush")) { g_ctx.opt_mbox_flush = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "host_copy_kernels")) { g_ctx.opt_host_copy_kernels = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
@@ -1817,6 +1851,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
                     P->L_cap = mpp * mpp;
                 }
                 count_h2d((size_t)mpp * mpp * sizeof(double));
+                note_dma();
                 BH_HIP(hipMemcpy2DAsync(P->L, (size_t)mpp * sizeof(double), L, (size_t)ldL * sizeof(double), (size_t)mpp * sizeof(double),
                                         (size_t)mpp, hipMemcpyHostToDevice, g_ctx.stream));
                 P->have_L = true;
@@ -1829,6 +1864,7 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
         return fail(BH_ERR_SHAPE, "mpp != count(fixvars) for mA == 0");
     }
     count_h2d((size_t)(P->ldA + nfix) * sizeof(int));
+    note_dma();
     BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
     if (nfix > 0) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), (size_t)nfix * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
     P->nfix = nfix; P->mpp = (int)want; P->reduced = reduced;
@@ -2224,6 +2260,7 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     BH_TRY(pcg_run(H, P, gp, wlp, wup, wp, !in_place, kappa2, atol_negcurv, atol_f2b, trace_cap, &fin, nullptr, !dev));
     if (!in_place) BH_TRY(fetch_vec(w_out, c.w, n, dev));
     if (trace_cap > 0) count_d2h((size_t)4 * trace_cap * sizeof(double));
+    if (trace_cap > 0) note_dma();
     if (trace_cap > 0) BH_HIP(hipMemcpyAsync(trace, c.d_trace, (size_t)4 * trace_cap * sizeof(double), hipMemcpyDeviceToHost, g_ctx.stream));
     // The final hipStreamSynchronize costs ~10 us (measured: 650 -> 640 us per config-3 subproblem).  It is skipped when nothing
     // can still be written: device vectors used in place (no staged result to fetch), no trace, and the loop stopped in the
@@ -2597,6 +2634,7 @@ static int32_t adopt_device_mask(bh_proj* P, uint64_t* fix_chunks_out, int* info
         hipLaunchKernelGGL(canon_mask_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->fixrank, P->fixidx, (int)n, (int)P->ldA, P->chunks_dev, P->counts);
         BH_HIP(hipGetLastError());
         count_d2h(nwords * sizeof(uint64_t) + sizeof(counts));
+        note_dma();
         BH_HIP(hipMemcpyAsync(chunks.data(), P->chunks_dev, nwords * sizeof(uint64_t), hipMemcpyDeviceToHost, g_ctx.stream));
         BH_HIP(hipMemcpyAsync(counts, P->counts, (with_info ? 5 : 4) * sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
         BH_TRY(sync_flush());
@@ -2758,6 +2796,7 @@ int32_t bh_dev_upload(void* dst_dev, const void* src_host, int64_t bytes) {
     if (bytes < 0 || (bytes > 0 && (!dst_dev || !src_host))) return fail(BH_ERR_INVALID_ARG, "bad argument");
     if (bytes == 0) return BH_OK;
     count_h2d((size_t)bytes);
+    note_dma();
     BH_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, g_ctx.stream));
     BH_TRY(sync_flush());
     return BH_OK;
@@ -2767,6 +2806,7 @@ int32_t bh_dev_download(void* dst_host, const void* src_dev, int64_t bytes) {
     if (bytes < 0 || (bytes > 0 && (!dst_host || !src_dev))) return fail(BH_ERR_INVALID_ARG, "bad argument");
     if (bytes == 0) return BH_OK;
     count_d2h((size_t)bytes);
+    note_dma();
     BH_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     BH_TRY(sync_flush());
     return BH_OK;
@@ -2865,6 +2905,7 @@ int32_t bh_selftest(void) {
     BH_REQUIRE_INIT();
     double host_in[256], host_out[512];
     for (int i = 0; i < 256; ++i) host_in[i] = (double)((i * 37) % 101) - 50.0 + 1.0 / (double)(i + 3);
+    note_dma();
     BH_HIP(hipMemcpyAsync(g_ctx.scratch_dev, host_in, sizeof(host_in), hipMemcpyHostToDevice, g_ctx.stream));
     hipLaunchKernelGGL(selftest_wave_kernel, dim3(1), dim3(256), 0, g_ctx.stream, g_ctx.scratch_dev, g_ctx.scratch_dev + 256);
     BH_HIP(hipMemcpyAsync(host_out, g_ctx.scratch_dev + 256, sizeof(host_out), hipMemcpyDeviceToHost, g_ctx.stream));

@@ -311,6 +311,10 @@ int32_t bh_stats_reset(bh_hess* H);
  *                          host nothing and return once their work is enqueued.
  *                        A caller's device vector is read where it lies when it needs no padding (n a multiple of 16, 16-byte
  *                        aligned); every other case, and every host-pointer entry point, behaves as before.
+ *   "host_copy_kernels" [1] host-pointer entry points: the caller's vectors travel between the pinned arena and HBM by a small
+ *                        copy kernel on the mapped arena instead of a DMA engine transfer, and the call ends with a mailbox seal +
+ *                        poll instead of hipStreamSynchronize (bh_pcg 0.660 -> 0.652 ms, bh_minor_iterate 0.693 -> 0.665 ms,
+ *                        bh_project 31 -> 21 us on the config-3 instance); 0 = DMA + synchronize (round 1)
  *   "mailbox_flush"  [0] experiment: end the host-pointer entry points with a mailbox seal + poll instead of
  *                        hipStreamSynchronize (measured slower behind a D2H DMA)
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
