@@ -1821,12 +1821,14 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     BH_REQUIRE_INIT();
     if (!P) return fail(BH_ERR_INVALID_ARG, "NULL bh_proj");
     if (n != P->n) return fail(BH_ERR_SHAPE, "fixvars length differs from n");
-    std::vector<int> rank((size_t)P->ldA, -1), idx;
+    int nfix = 0;
     if (fix_chunks) {
-        for (int64_t i = 0; i < n; ++i)
-            if ((fix_chunks[i >> 6] >> (i & 63)) & 1ull) { rank[(size_t)i] = (int)idx.size(); idx.push_back((int)i); }
+        for (int64_t wd = 0; wd < (n + 63) / 64; ++wd) {
+            uint64_t bits = fix_chunks[wd];
+            if (wd == (n + 63) / 64 - 1 && (n & 63)) bits &= (1ull << (n & 63)) - 1ull;      // stray bits beyond n do not count
+            nfix += __builtin_popcountll(bits);
+        }
     }
-    const int nfix = (int)idx.size();
     const int64_t want = P->mA + nfix;
     const size_t nwords = (size_t)((n + 63) / 64);
     {   // The Julia shim re-pushes before every projection; with the reduced form (or no linear rows) the device state
@@ -1863,20 +1865,50 @@ int32_t bh_proj_set_active(bh_proj* P, const uint64_t* fix_chunks, int64_t n, co
     } else if (mpp != want && L != nullptr) {
         return fail(BH_ERR_SHAPE, "mpp != count(fixvars) for mA == 0");
     }
-    count_h2d((size_t)(P->ldA + nfix) * sizeof(int));
-    note_dma();
-    BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
-    if (nfix > 0) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), (size_t)nfix * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+    // The mask goes up as the BitVector image it arrived as (n/8 bytes, through the pinned arena and a copy-free kernel read);
+    // two small kernels expand it into fixrank / fixidx on the device.  (Fallback without a mapped arena: expanded on the host.)
+    double* pin = arena_kernels() ? pin_alloc((int64_t)nwords) : nullptr;
+    if (pin != nullptr) {
+        if (fix_chunks) memcpy(pin, fix_chunks, nwords * sizeof(uint64_t));
+        else memset(pin, 0, nwords * sizeof(uint64_t));
+        count_h2d(nwords * sizeof(uint64_t));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((P->ldA + 255) / 256, 256));
+        hipLaunchKernelGGL(flags_from_chunks_kernel, dim3(grid), dim3(256), 0, g_ctx.stream,
+                           reinterpret_cast<const unsigned long long*>(pin_dev_view(pin)), P->fixrank, (int)n, (int)P->ldA);
+        hipLaunchKernelGGL(canon_mask_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, P->fixrank, P->fixidx, (int)n, (int)P->ldA,
+                           (unsigned long long*)nullptr, P->counts);
+        BH_HIP(hipGetLastError());
+    } else {
+        std::vector<int> rank((size_t)P->ldA, -1), idx;
+        if (fix_chunks) {
+            for (int64_t i = 0; i < n; ++i)
+                if ((fix_chunks[i >> 6] >> (i & 63)) & 1ull) { rank[(size_t)i] = (int)idx.size(); idx.push_back((int)i); }
+        }
+        count_h2d((size_t)(P->ldA + nfix) * sizeof(int));
+        note_dma();
+        BH_HIP(hipMemcpyAsync(P->fixrank, rank.data(), (size_t)P->ldA * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+        if (nfix > 0) BH_HIP(hipMemcpyAsync(P->fixidx, idx.data(), (size_t)nfix * sizeof(int), hipMemcpyHostToDevice, g_ctx.stream));
+        BH_HIP(hipStreamSynchronize(g_ctx.stream));          // rank / idx are locals of this block
+    }
     P->nfix = nfix; P->mpp = (int)want; P->reduced = reduced;
     int info_host = 0;
     if (reduced) {
         // reduced form: factor A_free A_free' (mA x mA) on the device; bound changes need no host factor
         BH_TRY(ensure_reduced_buffers(P));
         BH_TRY(launch_reduced_factor(P, nfix > 0, nullptr));
-        count_d2h(sizeof(int));
-        BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
     }
-    BH_TRY(sync_flush());   // host vectors go out of scope
+    if (reduced && !g_pin.dma && g_ctx.mbox_h != nullptr) {
+        // the factorisation flag rides to the host with the seal that ends the call
+        BH_TRY(mbox_seal_and_wait(sizeof(int), nullptr, nullptr, nullptr, P->info, 1, mbox_dev<int>(kMbInts)));
+        info_host = mbox_host<int>(kMbInts)[0];
+    } else {
+        if (reduced) {
+            count_d2h(sizeof(int));
+            note_dma();
+            BH_HIP(hipMemcpyAsync(&info_host, P->info, sizeof(int), hipMemcpyDeviceToHost, g_ctx.stream));
+        }
+        BH_TRY(sync_flush());   // host vectors go out of scope
+    }
     if (info_host != 0) {
         P->active_set = false;
         return fail(BH_ERR_PRECONDITION, "A_free*A_free' is not positive definite (PosDefException in the reference's cholesky)");

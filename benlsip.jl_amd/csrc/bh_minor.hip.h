@@ -117,6 +117,13 @@ __global__ __launch_bounds__(CG_T) void canon_mask_kernel(int* __restrict__ fixr
     if (threadIdx.x == 0) counts[AU_FIXED] = total;
 }
 
+// fixflag[i] = 0 where bit i of the BitVector image is set (fixed), -1 elsewhere (free, and the padding): the host pushes n/8
+// bytes instead of an expanded int array; canon_mask_kernel then numbers the fixed variables.
+__global__ __launch_bounds__(256) void flags_from_chunks_kernel(const unsigned long long* __restrict__ chunks, int* __restrict__ fixflag, int n, int n_pad) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_pad; i += gridDim.x * 256)
+        fixflag[i] = (i < n && ((chunks[i >> 6] >> (i & 63)) & 1ull)) ? 0 : -1;
+}
+
 // M <- M - sum_j a_j a_j', j over the variables that have just become fixed (newidx[0 .. counts[AU_NEW]), index order):
 // A_free A_free' after add_active!(indices), without touching the other n - |new| columns of A.
 __global__ __launch_bounds__(256) void gram_downdate_list_kernel(double* __restrict__ M, const double* __restrict__ A, int64_t ldA, int mA,
