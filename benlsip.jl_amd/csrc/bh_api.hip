@@ -2368,11 +2368,26 @@ static int32_t linesearch_impl(bh_hess* H, bh_proj* P, const double* g_model, co
     const int64_t n = H->n;
     BH_TRY(ensure_cg_workspace(H->ld, 0));
     CgWorkspace& c = g_ctx.cg;
+    if (dev) {
+        // the line-search kernel reads its vectors element by element (used where they lie); only vthv(H, w) needs w in whole
+        // 16-byte chunks up to the padded length
+        const double* wp = c.w;
+        if (n == H->ld && (reinterpret_cast<uintptr_t>(w) & 15u) == 0) wp = w;
+        else {
+            BH_HIP(hipMemsetAsync(c.w, 0, (size_t)H->ld * sizeof(double), g_ctx.stream));
+            BH_TRY(stage_vec(c.w, w, n, true));
+        }
+        BH_TRY(mbox_ensure());
+        BH_TRY(launch_linesearch(H, P, g_model, const_cast<double*>(wp), w_l, w_u, false, nullptr, mbox_dev<double>(kMbScal)));
+        BH_TRY(mbox_seal_and_wait(sizeof(double)));
+        *alpha_out = *mbox_host<double>(kMbScal);
+        return BH_OK;
+    }
     BH_HIP(hipMemsetAsync(c.w, 0, (size_t)H->ld * sizeof(double), g_ctx.stream));
-    BH_TRY(stage_vec(c.w, w, n, dev));
-    BH_TRY(stage_vec(c.g, g_model, n, dev));
-    BH_TRY(stage_vec(c.wl, w_l, n, dev));
-    BH_TRY(stage_vec(c.wu, w_u, n, dev));
+    BH_TRY(stage_vec(c.w, w, n, false));
+    BH_TRY(stage_vec(c.g, g_model, n, false));
+    BH_TRY(stage_vec(c.wl, w_l, n, false));
+    BH_TRY(stage_vec(c.wu, w_u, n, false));
     BH_TRY(launch_linesearch(H, P, c.g, c.w, c.wl, c.wu, false));
     BH_TRY(fetch_vec(alpha_out, c.scalars, 1, false));
     BH_TRY(sync_flush());
@@ -2704,17 +2719,12 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         if (lds > kLdsPerCu) return fail(BH_ERR_UNSUPPORTED, "factor too large for the single-workgroup triangular solve");
         BH_TRY(ensure_trsv_lds(lds));
     }
-    if (!dev) {
-        BH_TRY(stage_vecs(c.x, {x, xlow, xupp, g}, n, c.n_pad));                   // c.x, c.xlow, c.xupp, c.g are consecutive
-    } else {
-        BH_TRY(stage_vec(c.x, x, n, true));
-        BH_TRY(stage_vec(c.g, g, n, true));
-        BH_TRY(stage_vec(c.xlow, xlow, n, true));
-        BH_TRY(stage_vec(c.xupp, xupp, n, true));
-    }
+    // (the Cauchy kernels read x, g and the bounds element by element: a device caller's vectors are used where they lie)
+    if (!dev) BH_TRY(stage_vecs(c.x, {x, xlow, xupp, g}, n, c.n_pad));            // c.x, c.xlow, c.xupp, c.g are consecutive
 
     CauchyArgs a{};
-    a.st = c.d_state; a.x = c.x; a.g = c.g; a.xlow = c.xlow; a.xupp = c.xupp;
+    a.st = c.d_state;
+    a.x = dev ? x : c.x; a.g = dev ? g : c.g; a.xlow = dev ? xlow : c.xlow; a.xupp = dev ? xupp : c.xupp;
     a.negg = c.r; a.d = c.p; a.Hd = c.Hp; a.s = c.w; a.dl = c.wl; a.du = c.wu;
     a.fixrank = P->fixrank; a.n = (int)n; a.n_pad = (int)H->ld; a.nmm = (int)(n - mA);
     a.delta = delta; a.atol = std::sqrt(2.220446049250313e-16);
