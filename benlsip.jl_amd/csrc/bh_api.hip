@@ -978,6 +978,9 @@ int32_t mbox_poll(unsigned long long seq) {
                 return fail(BH_ERR_HIP, "mailbox wait: no progress for 120 s", /*drain=*/false);
         }
     }
+    // what the device wrote before the seal (mailbox payload, results parked in the pinned arena) is read after it: keep the
+    // compiler from hoisting those plain loads above the poll (the hardware keeps load order on its own)
+    std::atomic_thread_fence(std::memory_order_acquire);
     return BH_OK;
 }
 void pin_arena_deliver() {
