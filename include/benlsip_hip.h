@@ -293,8 +293,9 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        (needs the caller's factor in bh_proj_set_active)
  *   "pcg_batch"      [0] CG iterations enqueued per launch-ahead batch; 0 = by problem size (1 when an H*p streams >= 100 us)
  *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
- *   "cg_fused"       [1] box constraints on one rank: two kernels per CG iteration (the H*p launch forms p and takes the exit test,
- *                        one kernel reduces the slabs and updates w, r, v) instead of three (H*p, slab reduction, step kernel);
+ *   "cg_fused"       [1] box constraints (one rank, or several over the peer-buffer transport): two kernels per CG iteration (the
+ *                        H*p launch forms p and takes the exit test, one kernel reduces the slabs — exchanging them between the
+ *                        ranks — and updates w, r, v) instead of three (H*p, slab reduction, step kernel);
  *                        2: also linear equalities (reduced form, mA <= 64): four kernels instead of seven; 0: the round-1 shapes
  *   "final_sync"     [0] device-pointer entry points (*_dev): 1 = always drain the library stream before returning, as the
  *                        host-pointer entry points do.  0 = return as soon as everything the HOST is owed has arrived; results

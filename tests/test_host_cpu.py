@@ -105,3 +105,18 @@ def test_options_and_argument_checks_without_gpu():
     assert lib.bh_comm_info(C.byref(r), C.byref(n)) == 0 and (r.value, n.value) == (0, 1)
     for code in range(0, -9, -1):
         assert len(lib.bh_strerror(code)) > 0
+
+
+def test_every_option_key_is_documented_in_the_header():
+    """Every key bh_set_option accepts (csrc/bh_api.hip) appears, quoted, in the option list of include/benlsip_hip.h — and the
+    header documents no key the library does not know."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "benlsip.jl_amd", "csrc", "bh_api.hip")).read()
+    hdr = open(os.path.join(root, "include", "benlsip_hip.h")).read()
+    accepted = set(re.findall(r'!strcmp\(key, "([a-z_]+)"\)', src))
+    assert len(accepted) >= 15
+    i = hdr.index("int32_t bh_set_option(")
+    documented = set(re.findall(r'^ \*   "([a-z_]+)"', hdr[hdr.rindex("/*", 0, i):i], flags=re.M))
+    assert accepted - documented == set(), "options without a line in the header: %s" % sorted(accepted - documented)
+    assert documented - accepted == set(), "header documents unknown options: %s" % sorted(documented - accepted)
