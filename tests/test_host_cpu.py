@@ -120,3 +120,19 @@ def test_every_option_key_is_documented_in_the_header():
     documented = set(re.findall(r'^ \*   "([a-z_]+)"', hdr[hdr.rindex("/*", 0, i):i], flags=re.M))
     assert accepted - documented == set(), "options without a line in the header: %s" % sorted(accepted - documented)
     assert documented - accepted == set(), "header documents unknown options: %s" % sorted(documented - accepted)
+
+
+def test_tools_and_product_never_touch_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it.  No script
+    under tools/ and no file of the product package mentions the oracle modules."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for pat in ("tools/*.py", "tools/*.sh", "tools/*/*.sh", "tools/*/*.py", "benlsip.jl_amd/*.py", "benlsip.jl_amd/csrc/*", "julia/*.jl", "examples/*"):
+        for f in glob.glob(os.path.join(root, pat)):
+            if not os.path.isfile(f):
+                continue
+            text = open(f, errors="replace").read()
+            if "benlsip_ref" in text or "benlsip_oracle" in text or "oracle/" in text or 'join(ROOT, "oracle")' in text:
+                offenders.append(os.path.relpath(f, root))
+    assert offenders == [], offenders
