@@ -166,6 +166,9 @@ bool pin_arena_busy();
 // (the arena is then retired instead of reused).
 int32_t fail(int32_t code, const std::string& what, bool drain = true) {
     g_ctx.detail = what;
+    // the runtime keeps the last error until somebody reads it: a failed hipMalloc (out of memory) would otherwise surface
+    // again in the next call's hipGetLastError() check and fail a perfectly good launch
+    (void)hipGetLastError();
     bool drained = true;
     if (pin_arena_busy()) drained = drain && g_ctx.stream != nullptr && hipStreamSynchronize(g_ctx.stream) == hipSuccess;
     pin_arena_abandon(drained);

@@ -101,6 +101,19 @@ def test_caller_supplied_stream(bh):
     assert np.array_equal(H * g, hv0)
 
 
+def test_out_of_memory_is_an_error_not_a_state(bh):
+    """An image that cannot fit the 288 GB of HBM (12M x 4096 doubles = 393 GB) is refused with BH_ERR_HIP, and the next call works:
+    the runtime's sticky last-error must not leak into it (it did once: the following bh_hmul failed with 'out of memory')."""
+    with pytest.raises(bh.BenlsipHipError) as e:
+        bh.AlHessian.synthetic(12_000_000, 4096, seed=1, mu=1.0)
+    assert "memory" in str(e.value).lower()
+    J = np.random.default_rng(0).standard_normal((500, 64))
+    H = bh.AlHessian(J, None, 1.0)
+    v = np.ones(64)
+    assert relnorm(H * v, J.T @ (J @ v)) <= 1e-12
+    H.close()
+
+
 def test_linearity_and_symmetry_at_full_size(bh):
     """Size-independent properties at BASELINE config 3 (d=65536, n=4096; J generated in HBM):
     H(av+bw) = aHv + bHw, v'Hw = w'Hv, v'Hv = vthv(H,v) = ||Jv||^2, and J rows check against the host generator."""
