@@ -101,6 +101,26 @@ def test_caller_supplied_stream(bh):
     assert np.array_equal(H * g, hv0)
 
 
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_non_finite_gradient_runs_the_loop_out_like_the_reference(bh, cg_fused, bad):
+    """A NaN / Inf in g_minor makes every comparison of the loop false (src/basic_tralcnlss.jl:725, :735, :747): the reference
+    iterates until `iter > max_iter` and returns `nothing` with NaN in w.  Same exit, same iteration count, same NaN pattern."""
+    rng = np.random.default_rng(1)
+    n, d = 40, 200
+    J = rng.standard_normal((d, n))
+    g = rng.standard_normal(n)
+    g[3] = bad
+    A = np.zeros((0, n))
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), None, l=-np.ones(n), u=np.ones(n))
+    with np.errstate(all="ignore"):
+        w_ref, s_ref, it_ref = R.projected_cg(g, R.AlHessian(J, np.zeros((0, n)), 1.0), -np.ones(n), np.ones(n), cons_o, 0.1)
+    H = bh.AlHessian(J, None, 1.0)
+    w, st, info = bh.projected_cg(g, H, -np.ones(n), np.ones(n), bh.MixedConstraints(A, None, None), 0.1, full_output=True)
+    assert int(st) == int(s_ref) == int(R.CGStatus.none) and info["iters"] == it_ref == 2 * n + 1
+    assert np.array_equal(np.isnan(w), np.isnan(w_ref)) and np.isnan(w).any()
+    H.close()
+
+
 def test_out_of_memory_is_an_error_not_a_state(bh):
     """An image that cannot fit the 288 GB of HBM (12M x 4096 doubles = 393 GB) is refused with BH_ERR_HIP, and the next call works:
     the runtime's sticky last-error must not leak into it (it did once: the following bh_hmul failed with 'out of memory')."""
