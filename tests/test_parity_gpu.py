@@ -121,6 +121,13 @@ def test_non_finite_gradient_runs_the_loop_out_like_the_reference(bh, cg_fused, 
     H.close()
 
 
+def test_degenerate_shapes_match_the_oracle(bh, cg_fused):
+    """No residual rows (d = 0, with and without C), n = 1 and 2, every variable fixed, no degrees of freedom left (mA + p = n),
+    mu = 0, a single row: H*v, vthv, projection and projected_cg against the oracle (tests/edge_shapes_check.py)."""
+    import edge_shapes_check
+    assert edge_shapes_check.run(bh, cg_fused) == []
+
+
 def test_out_of_memory_is_an_error_not_a_state(bh):
     """An image that cannot fit the 288 GB of HBM (12M x 4096 doubles = 393 GB) is refused with BH_ERR_HIP, and the next call works:
     the runtime's sticky last-error must not leak into it (it did once: the following bh_hmul failed with 'out of memory')."""
