@@ -173,6 +173,26 @@ def test_whole_row_sharded_solve_matches_unsharded_oracle(tmp_path, capsys, name
     assert np.linalg.norm(P["c"](xs[0]["x"])) < 1e-6 and np.linalg.norm(P["A"] @ xs[0]["x"] - P["b"]) < 1e-10
 
 
+@pytest.mark.parametrize("comm", ["ipc", "staged"])
+def test_ranks_without_rows(tmp_path, comm):
+    """Fewer rows than ranks (d_total = 2 over 3 ranks: the last rank owns nothing): products and a whole projected_cg are
+    still all-reduced, replicas bit-identical, equal to the unsharded oracle."""
+    world = 3
+    run_ranks("zero_rows_worker.py", world, tmp_path, comm)
+    res = [np.load(os.path.join(tmp_path, "zero_rank%d.npz" % r)) for r in range(world)]
+    assert int(res[2]["hi"]) - int(res[2]["lo"]) == 0
+    for r in range(1, world):
+        for key in ("hv", "vt", "w", "st", "it"):
+            assert np.array_equal(res[0][key], res[r][key]), (r, key)
+    rng = np.random.default_rng(5)
+    J = rng.standard_normal((2, 24)); C = rng.standard_normal((1, 24)); g = rng.standard_normal(24)
+    Ho = R.AlHessian(J, C, 2.0)
+    assert relnorm(res[0]["hv"], R.hmul(Ho, g)) <= 1e-12 and float(res[0]["vt"]) == pytest.approx(R.vthv(Ho, g), rel=1e-12)
+    Z = np.zeros((0, 24))
+    w, st, it = R.projected_cg(g, Ho, -np.ones(24), np.ones(24), R.make_mixed_constraints(Z, R.chol_lower(Z @ Z.T), None, l=-np.ones(24), u=np.ones(24)), 1e-3)
+    assert int(res[0]["st"]) == int(st) and int(res[0]["it"]) == it and relnorm(res[0]["w"], w) <= 1e-8
+
+
 def test_launch_schedule_is_rank_independent_at_a_batch_threshold(tmp_path):
     """shards of 21363 / 21362 / 21362 rows at n = 4096 put rank 0's own streaming-time estimate above the 100 us
     launch-ahead threshold and the others' below it.  Over the RCCL call site (the stand-in fails on unmatched collectives)
