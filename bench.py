@@ -306,9 +306,13 @@ def main():
             err = err or "a peer rank reported a library error"
         return float(g[:, 0].max()), out, (H.stats() if err is None else None), err
 
-    # short runs: time EVERY H*p launch with hipEvents (an event pair costs ~10 us of stream time, so long runs sample every 8th)
+    # hipEvents around H*p launches INSIDE the timed region: an event pair costs ~10 us of stream time, so bracketing every launch
+    # slows the loop it measures (measured at K = 20: 690 instead of 630 us per subproblem, -9 %).  Long runs sample every 8th
+    # launch, short ones every 4th (10 samples at K = 20, < 1 % cost); a DENSE pass outside the timed region (every launch of
+    # 16 subproblems) is reported next to it as roofline.dense_sample.
     st_probe = run_steps(bh, H, cons, dv, kappa2, 1)
-    bh.set_option("profile_stride", 1 if args.steps * st_probe[2] <= 64 else 8)
+    timed_stride = 4 if args.steps * st_probe[2] <= 64 else 8
+    bh.set_option("profile_stride", timed_stride)
     elapsed, out, st, run_err = timed_run(args.steps, args.warmup)
     if run_err is not None:                         # every rank sees the same verdict (gathered), so all of them stop here
         raise SystemExit("bench: the timed run failed: %s" % run_err)
@@ -360,6 +364,22 @@ def main():
         except bh.BenlsipHipError:
             pass
 
+    # dense sample, outside the timed region: every H*p launch of 16 subproblems bracketed by events (all ranks do the same calls)
+    dense = None
+    try:
+        bh.set_option("profile_stride", 1)
+        H.reset_stats()
+        run_steps(bh, H, cons, dv, kappa2, 16)
+        barrier_noexcept()
+        sd = H.stats()
+        if sd["hmul_timed"] > 0:
+            d_ms = sd["hmul_ms"] / sd["hmul_timed"]
+            dense = {"launches_timed": sd["hmul_timed"], "avg_launch_ms": d_ms, "achieved": sd["bytes_per_hmul"] / (d_ms * 1e-3) / 1e9,
+                     "note": "every H*p launch of 16 subproblems after the timed region, hipEvents on the launch stream"}
+    except bh.BenlsipHipError:
+        dense = None
+    bh.set_option("profile_stride", timed_stride)
+
     traffic, traffic_src = pmc_traffic() if world == 1 else (None, None)
     ms_per_step = 1e3 * elapsed / args.steps
     hmul_ms = st["hmul_ms"] / max(st["hmul_timed"], 1)
@@ -398,7 +418,7 @@ def main():
             "frac_of_guide_measured_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": st["bytes_per_hmul"], "avg_launch_ms": hmul_ms,
-            "launches_timed": st["hmul_timed"], "rank": rank,
+            "launches_timed": st["hmul_timed"], "timed_region_event_stride": timed_stride, "dense_sample": dense, "rank": rank,
             "achieved_min_over_ranks": float(per_rank[:, 0].min()), "achieved_max_over_ranks": float(per_rank[:, 0].max()),
             "per_rank": [{"rank": r, "achieved": float(per_rank[r, 0]), "avg_launch_ms": float(per_rank[r, 1]),
                           "algorithmic_bytes_per_launch": float(per_rank[r, 2]), "rows": int(per_rank[r, 3])} for r in range(world)],
