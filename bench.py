@@ -176,6 +176,65 @@ def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, repeats=5
     }
 
 
+def self_launch(n_ranks, argv, script=None):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes (one per GPU, the same
+    environment torch.distributed.run would give them: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay
+    rank 0's JSON line on stdout and everything else on stderr, and return the worst child exit code.  This process never
+    imports torch or the library and never touches HIP (tests/test_host_cpu.py checks that libamdhip64 is not mapped here),
+    so nothing that has initialised a GPU is ever replaced or forked.  A rank that dies takes the job with it: the
+    others are given a grace period (they may be waiting in a collective for it) and are then killed by PID."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=env.get("MASTER_PORT", str(port)), BH_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cpu_share() // n_ranks)))
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1))
+
+    def relay(r, stream, is_out):
+        for ln in stream:
+            if is_out and r == 0:
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write("[rank %d] %s" % (r, ln))
+                sys.stderr.flush()
+
+    threads = [threading.Thread(target=relay, args=(r, s, o), daemon=True)
+               for r, p in enumerate(procs) for s, o in ((p.stdout, True), (p.stderr, False))]
+    for t in threads:
+        t.start()
+    grace = float(os.environ.get("BH_BENCH_PEER_GRACE_S", "60"))
+    rcs, first_fail = [None] * n_ranks, None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and first_fail is None:
+                    first_fail = time.monotonic()
+                    sys.stderr.write("bench: rank %d exited with code %d\n" % (r, rcs[r]))
+        if first_fail is not None and time.monotonic() - first_fail > grace:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    sys.stderr.write("bench: killing rank %d (pid %d), %g s after a peer failed\n" % (r, p.pid, grace))
+                    p.kill()
+            first_fail = float("inf")
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    bad = [rc for rc in rcs if rc != 0]
+    return 0 if not bad else (max(bad) if max(bad) > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +249,10 @@ def main():
     ap.add_argument("--no-ic-extra", action="store_true",
                     help="skip the ill-conditioned extra run (its over-launched no-op kernels would pull down rocprofv3's per-kernel average)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # typed as `python bench.py --gpus N`: be the launcher (before anything here imports torch or touches HIP)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     # keep idle BLAS worker teams within the CPU share: a 128-thread team spinning on a 16-CPU quota gets the whole
     # process throttled for tens of milliseconds at a time — also while it only drives the GPU
@@ -322,8 +385,11 @@ def main():
         launch-ahead schedule relies on it.  Compares a checksum of the bit patterns across ranks; returns
         (identical, this rank's w)."""
         w_host = dv["w"].download()
-        chk = float(int(np.bitwise_xor.reduce(w_host.view(np.int64))) % (1 << 52)) + float(it_) * 1e-3 + float(nh_) * 1e-6
-        allchk = gather([chk])
+        bits = w_host.view(np.uint64)
+        x = int(np.bitwise_xor.reduce(bits))
+        s = int(np.add.reduce(bits * (np.arange(bits.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))))   # position-weighted, wraps mod 2^64
+        # every field below is an integer < 2^32, exactly representable in the float64 the gather carries
+        allchk = gather([float(x >> 32), float(x & 0xFFFFFFFF), float(s >> 32), float(s & 0xFFFFFFFF), float(it_), float(nh_)])
         return bool(np.all(allchk == allchk[0])), w_host
 
     replicas_identical, w_headline = None, None

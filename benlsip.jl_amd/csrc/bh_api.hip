@@ -1437,7 +1437,10 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
     pc.inbox_bytes = kPeerSlotBytes + kPeerFlagBytes + kPeerScalBytes + 256;
     hipError_t e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&pc.inbox, pc.inbox_bytes, hipDeviceMallocFinegrained); }
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(&pc.inbox, pc.inbox_bytes); }
+    // no coarse-grained fallback: the exchange kernels issue no cache-invalidating acquire and no L2 write-back (their
+    // system-scope accesses rely on memory that is not cached in a local L2), so on a plain hipMalloc'ed inbox flag polls and
+    // payload loads could be served from a stale line.  The rendezvous fails instead (collectively) and callers use RCCL.
+    if (e != hipSuccess) { (void)hipGetLastError(); pc.inbox = nullptr; }
     bool ok = (e == hipSuccess);
     if (ok) ok = hipMemset(pc.inbox, 0, pc.inbox_bytes) == hipSuccess;
     char* base = static_cast<char*>(pc.inbox);
@@ -1446,7 +1449,7 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
     if (ok) ok = hipDeviceSynchronize() == hipSuccess;
     if (ok && nranks > 1) ok = hipIpcGetMemHandle(&pc.shm->handle[rank], pc.inbox) == hipSuccess;
     if (!ok) pc.shm->failed = 1;
-    if (!peer_barrier(pc.shm, nranks, 120)) { peer_release(false); return fail(BH_ERR_RCCL, "peer rendezvous: the other ranks did not arrive (same node? same id?)"); }
+    if (!peer_barrier(pc.shm, nranks, 120)) { shm_unlink(name); peer_release(false); return fail(BH_ERR_RCCL, "peer rendezvous: the other ranks did not arrive (same node? same id?)"); }
     for (int p = 0; p < nranks && !pc.shm->failed; ++p) {
         if (p == rank) { pc.peer_base[p] = pc.inbox; continue; }
         if (hipIpcOpenMemHandle(&pc.peer_base[p], pc.shm->handle[p], hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
@@ -1456,14 +1459,18 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
         }
     }
     const bool met = peer_barrier(pc.shm, nranks, 120);
-    if (rank == 0) shm_unlink(name);           // everybody has mapped the page; nothing is left behind in /dev/shm
+    if (rank == 0 || !met) shm_unlink(name);   // everybody has mapped the page; nothing is left behind in /dev/shm (also on the failure exits)
     if (!met || pc.shm->failed) { peer_release(false); return fail(BH_ERR_RCCL, "peer rendezvous: hipIpc handle exchange failed on some rank"); }
+    // from here on every failure is made COLLECTIVE (flag on the shared page + barrier) so that all ranks leave together
     void* hp = nullptr;
-    if (hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { peer_release(false); return fail(BH_ERR_HIP, "hipHostMalloc(peer error word)"); }
-    memset(hp, 0, 64);
-    pc.h_err = static_cast<volatile unsigned long long*>(hp);
     void* dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { peer_release(false); return fail(BH_ERR_HIP, "hipHostGetDevicePointer(peer error word)"); }
+    bool local_ok = hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (local_ok) {
+        memset(hp, 0, 64);
+        pc.h_err = static_cast<volatile unsigned long long*>(hp);
+        local_ok = hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess;
+    }
+    if (!local_ok) { (void)hipGetLastError(); pc.shm->failed = 1; }
     PeerArgs& a = pc.args;
     a = PeerArgs{};
     for (int p = 0; p < nranks; ++p) {
@@ -1479,6 +1486,45 @@ static int32_t peer_init(int rank, int nranks, const unsigned char* id) {
     a.rank = rank; a.nranks = nranks; a.cap = kPeerCap; a.nblk_cap = kPeerBlkCap;
     const char* ts = getenv("BH_PEER_TIMEOUT_S");
     a.timeout_ticks = (unsigned long long)((ts && atof(ts) > 0 ? atof(ts) : 20.0) * 1e8);            // wall_clock64: 100 MHz
+    // Reachability echo (a mapping that opens is not yet a mapping stores land in): one real exchange of a known vector
+    // through every mapped inbox, with a short timeout, BEFORE anybody relies on the transport — a node where hipIpc maps
+    // but peer stores do not arrive is found here, collectively, and callers fall back to RCCL instead of running into the
+    // in-kernel timeout inside a timed region.  Rank r contributes (r + 1)(i + 1); the sum is exact in fp64.
+    std::string echo_detail;
+    const bool met1 = peer_barrier(pc.shm, nranks, 120);          // every rank's `failed` so far is visible behind it
+    const char* skip = getenv("BH_PEER_ECHO_SKIP_RANK");          // test hook: this rank stays away from the echo
+    if (met1 && !pc.shm->failed && skip && *skip && atoi(skip) == rank) {
+        echo_detail = "this rank stayed away from the echo (BH_PEER_ECHO_SKIP_RANK)";
+        pc.shm->failed = 1;
+    } else if (met1 && !pc.shm->failed) {
+        constexpr int kEcho = 2 * kPeerBlockChunks;               // one workgroup's worth
+        double hv[kEcho], *dv = nullptr;
+        for (int i = 0; i < kEcho; ++i) hv[i] = (double)(rank + 1) * (double)(i + 1);
+        bool ok_e = hipMalloc(&dv, sizeof(hv)) == hipSuccess && hipMemcpy(dv, hv, sizeof(hv), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok_e) {
+            PeerArgs ea = a;
+            const char* es = getenv("BH_PEER_ECHO_TIMEOUT_S");
+            ea.timeout_ticks = (unsigned long long)((es && atof(es) > 0 ? atof(es) : 5.0) * 1e8);
+            hipLaunchKernelGGL(reduce_exchange_kernel, dim3(1), dim3(256), 0, g_ctx.stream, (const double*)nullptr, (int64_t)0, kPeerBlockChunks, 0, dv,
+                               (const CgState*)nullptr, ea);
+            ok_e = hipGetLastError() == hipSuccess && hipStreamSynchronize(g_ctx.stream) == hipSuccess &&
+                   hipMemcpy(hv, dv, sizeof(hv), hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (dv) (void)hipFree(dv);
+        if (!ok_e) { (void)hipGetLastError(); echo_detail = "the echo exchange could not run"; }
+        else if (*pc.h_err != 0ull) echo_detail = "the echo exchange timed out waiting for a peer's flag";
+        else
+            for (int i = 0; i < kEcho && echo_detail.empty(); ++i)
+                if (hv[i] != 0.5 * nranks * (nranks + 1) * (i + 1)) echo_detail = "the echo exchange returned a wrong sum (a peer's stores did not land)";
+        if (!echo_detail.empty()) pc.shm->failed = 1;
+    } else {
+        pc.shm->failed = 1;
+    }
+    const bool met2 = peer_barrier(pc.shm, nranks, 120);
+    if (!met2 || pc.shm->failed) {
+        peer_release(false);
+        return fail(BH_ERR_RCCL, "peer rendezvous: reachability check failed" + (echo_detail.empty() ? std::string(" on another rank") : ": " + echo_detail));
+    }
     pc.active = true;
     return BH_OK;
 }

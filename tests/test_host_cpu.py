@@ -1,4 +1,5 @@
 """CPU tests of the host logic and of the C-ABI library (load + exported symbols; no compute without a GPU)."""
+import json
 import os
 import re
 import subprocess
@@ -136,3 +137,48 @@ def test_tools_and_product_never_touch_the_oracle():
             if "benlsip_ref" in text or "benlsip_oracle" in text or "oracle/" in text or 'join(ROOT, "oracle")' in text:
                 offenders.append(os.path.relpath(f, root))
     assert offenders == [], offenders
+
+
+def test_bench_self_launch_never_touches_hip_in_the_parent(tmp_path):
+    """`python bench.py --gpus N` typed without a launcher starts its ranks as child processes; the launching process must
+    not have torch imported or libamdhip64 mapped (a process that has initialised the GPU must never be forked/replaced on
+    the GPU boxes), relays rank 0's stdout only, and returns the worst child exit code."""
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(
+        "import os, sys, json\n"
+        "r = int(os.environ['RANK']); w = int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "print(json.dumps({'rank': r, 'world': w, 'argv': sys.argv[1:]}), flush=True)\n"
+        "print('note from rank %d' % r, file=sys.stderr, flush=True)\n"
+        "sys.exit(int(os.environ.get('STUB_FAIL_RANK', '-1')) == r and 7 or 0)\n")
+    driver = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "rc = bench.self_launch(3, ['--gpus', '3', '--steps', '2'], script=%r)\n"
+        "maps = open('/proc/self/maps').read()\n"
+        "assert 'libamdhip64' not in maps and 'libbenlsip_hip' not in maps and 'librccl' not in maps, 'GPU runtime mapped in the launcher'\n"
+        "assert 'torch' not in sys.modules and 'benlsip_jl_amd' not in sys.modules\n"
+        "sys.exit(rc)\n" % (ROOT, str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, "-c", driver], env=env, capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0, ok.stderr
+    lines = [json.loads(ln) for ln in ok.stdout.splitlines()]
+    assert lines == [{"rank": 0, "world": 3, "argv": ["--gpus", "3", "--steps", "2"]}]          # rank 0's line only
+    assert all("[rank %d] note from rank %d" % (r, r) in ok.stderr for r in range(3))
+    bad = subprocess.run([sys.executable, "-c", driver], env=dict(env, STUB_FAIL_RANK="2"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 7 and "rank 2 exited with code 7" in bad.stderr
+
+
+def test_bench_gpus_n_as_typed_becomes_the_launcher():
+    """The command line of the driver's scaling leg, typed without torch.distributed.run, must reach the ranks (here, without
+    a GPU, every rank fails loudly in bh.init and the launcher reports a non-zero code instead of refusing to start)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(BH_BENCH_REHEARSAL="1", BH_BENCH_PEER_GRACE_S="5")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_multirank_gpu.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "launch with torch.distributed.run" not in r.stderr
+    assert "[rank 0]" in r.stderr and "[rank 1]" in r.stderr and "exited with code" in r.stderr

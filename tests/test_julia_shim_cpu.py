@@ -1,0 +1,158 @@
+"""Static check of julia/BEnlsipHIP.jl against include/benlsip_hip.h.
+
+No Julia toolchain exists in this pipeline, so the shim cannot be executed; what CAN be checked mechanically is the part whose
+failure mode is silent memory corruption: every `ccall((:bh_x, libbh), Ret, (types...), args...)` must name an export the
+header declares, with the same arity, the same return type, and per argument the same class — Int32 / Int64 / Float64 by
+value, or a pointer whose element type matches (`Ptr{Cvoid}` / `void*` match any pointer: handles and device addresses)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _split_top(s):
+    """Split on commas that are not nested inside (), {} or []."""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _balanced(text, i):
+    """text[i] == '(' -> index just past its matching ')', skipping string literals."""
+    depth, j, in_str = 0, i, False
+    while j < len(text):
+        ch = text[j]
+        if in_str:
+            if ch == "\\":
+                j += 1
+            elif ch == '"':
+                in_str = False
+        elif ch == '"':
+            in_str = True
+        elif ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+            if depth == 0:
+                return j + 1
+        j += 1
+    raise ValueError("unbalanced parenthesis at %d" % i)
+
+
+def julia_ccalls():
+    text = open(os.path.join(ROOT, "julia", "BEnlsipHIP.jl")).read()
+    text = "\n".join(ln if not ln.lstrip().startswith("#") else "" for ln in text.splitlines())
+    text = re.sub(r"#[^\n\"]*$", "", text, flags=re.M)          # trailing comments (none of them contains a quote)
+    calls = []
+    for m in re.finditer(r"\bccall\(", text):
+        end = _balanced(text, m.end() - 1)
+        parts = _split_top(text[m.end():end - 1])
+        sym = re.fullmatch(r"\(\s*:(\w+)\s*,\s*libbh\s*\)", parts[0])
+        assert sym, "ccall with an unexpected target: %s" % parts[0]
+        types = parts[2]
+        assert types.startswith("(") and types.endswith(")"), types
+        tlist = _split_top(types[1:-1])
+        calls.append(dict(name=sym.group(1), ret=parts[1], types=tlist, nargs=len(parts) - 3, line=text.count("\n", 0, m.start()) + 1))
+    return calls
+
+
+def header_prototypes():
+    text = open(os.path.join(ROOT, "include", "benlsip_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int32_t)\s+(bh_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        protos[name] = dict(ret="cstring" if "char" in ret else "i32", params=[c_class(p) for p in params], raw=params)
+    return protos
+
+
+def c_class(param):
+    p = param.replace("const ", "").strip()
+    stars = p.count("*")
+    base = re.match(r"(unsigned\s+long\s+long|\w+)", p).group(1)
+    if stars == 0:
+        return {"int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "double": "f64"}[base]
+    elem = {"double": "f64", "int32_t": "i32", "int64_t": "i64", "uint64_t": "u64", "void": "any", "char": "char",
+            "bh_hess": "any", "bh_proj": "any", "bh_stats_t": "any"}[base]
+    return "ptr:" + ("ptr" if stars == 2 else elem)
+
+
+def julia_class(t):
+    t = t.strip()
+    by_value = {"Int32": "i32", "Int64": "i64", "UInt64": "u64", "Float64": "f64"}
+    if t in by_value:
+        return by_value[t]
+    if t == "Cstring":
+        return "ptr:char"
+    m = re.fullmatch(r"(?:Ptr|Ref)\{(.+)\}", t)
+    assert m, "unrecognised ccall argument type %r" % t
+    inner = m.group(1)
+    if inner.startswith("Ptr{"):
+        return "ptr:ptr"
+    return "ptr:" + {"Float64": "f64", "Int32": "i32", "Int64": "i64", "UInt64": "u64", "UInt8": "any", "Cvoid": "any"}[inner]
+
+
+def compatible(jc, cc):
+    if jc == cc:
+        return True
+    if jc.startswith("ptr:") and cc.startswith("ptr:"):
+        j, c = jc[4:], cc[4:]
+        return (j == "any" and c != "ptr") or (c == "any" and j != "ptr")
+    return False
+
+
+def test_every_ccall_of_the_shim_matches_its_prototype():
+    calls, protos = julia_ccalls(), header_prototypes()
+    assert len(calls) >= 30 and len(protos) >= 60
+    problems = []
+    for c in calls:
+        where = "julia/BEnlsipHIP.jl:%d ccall(:%s)" % (c["line"], c["name"])
+        if c["name"] not in protos:
+            problems.append("%s: include/benlsip_hip.h declares no such export" % where)
+            continue
+        p = protos[c["name"]]
+        want_ret = "Cstring" if p["ret"] == "cstring" else "Int32"
+        if c["ret"] != want_ret:
+            problems.append("%s: return type %s, header says %s" % (where, c["ret"], want_ret))
+        if len(c["types"]) != len(p["params"]):
+            problems.append("%s: %d argument types, the prototype has %d parameters (%s)" % (where, len(c["types"]), len(p["params"]), ", ".join(p["raw"])))
+            continue
+        if c["nargs"] != len(c["types"]):
+            problems.append("%s: %d argument types but %d arguments" % (where, len(c["types"]), c["nargs"]))
+        for k, (jt, cc) in enumerate(zip(c["types"], p["params"])):
+            if not compatible(julia_class(jt), cc):
+                problems.append("%s: argument %d is %s, the prototype has `%s`" % (where, k + 1, jt, p["raw"][k]))
+    assert problems == [], "\n".join(problems)
+    used = {c["name"] for c in calls}
+    # the entry points the shim is built around must all be bound
+    for name in ("bh_init", "bh_hess_create", "bh_hess_destroy", "bh_hess_set_mu", "bh_hmul", "bh_vthv", "bh_proj_create", "bh_proj_set_active",
+                 "bh_proj_destroy", "bh_project", "bh_pcg", "bh_minor_iterate", "bh_cauchy_step", "bh_grad", "bh_resid_sqnorm",
+                 "bh_comm_unique_id", "bh_comm_init", "bh_comm_destroy", "bh_strerror", "bh_last_error_detail"):
+        assert name in used, "the shim never calls %s" % name
+
+
+def test_the_checker_catches_a_transposed_argument():
+    """The check must be able to fail: swap an Int64 and a Float64 of bh_pcg's tuple and it has to notice."""
+    protos = header_prototypes()
+    p = protos["bh_pcg"]
+    types = ["Ptr{Cvoid}", "Ptr{Cvoid}", "Ptr{Float64}", "Ptr{Float64}", "Ptr{Float64}", "Float64", "Float64", "Float64",
+             "Ptr{Float64}", "Ref{Int32}", "Ref{Int32}", "Ptr{Float64}", "Int64", "Ref{Int32}"]
+    assert all(compatible(julia_class(t), c) for t, c in zip(types, p["params"])) and len(types) == len(p["params"])
+    bad = list(types)
+    bad[7], bad[12] = bad[12], bad[7]
+    assert not all(compatible(julia_class(t), c) for t, c in zip(bad, p["params"]))
+    assert not compatible(julia_class("Ref{Int32}"), "ptr:f64") and not compatible(julia_class("Ref{Ptr{Cvoid}}"), "ptr:any")
+    assert compatible(julia_class("Ptr{Cvoid}"), "ptr:f64") and compatible(julia_class("Ptr{UInt8}"), "ptr:any")

@@ -238,3 +238,50 @@ def test_peer_exchange_soak_with_skewed_arrivals(tmp_path, world):
     for z in res:
         assert float(z["worst"]) <= 1e-12, float(z["worst"])
     assert all(int(z["digest"]) == int(res[0]["digest"]) for z in res)
+
+
+def test_unreachable_peer_inbox_fails_bh_comm_init_collectively(tmp_path):
+    """VERDICT r2 missing #2: a mapping that opens is not yet a mapping stores land in.  bh_comm_init ends with one real exchange
+    of a known vector through every mapped inbox (short timeout); when it fails on ANY rank (here: rank 1 stays away from it)
+    EVERY rank's bh_comm_init fails, before anybody relies on the transport — bench.py then falls back to RCCL ahead of its
+    timed region.  The library stays usable and no rendezvous page is left in /dev/shm."""
+    world = 2
+    env, _ = comm_env("ipc")
+    env.update(BH_PEER_ECHO_SKIP_RANK="1", BH_PEER_ECHO_TIMEOUT_S="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(MR, "echo_worker.py"), str(r), str(world), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=180)[0] for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-2000:])
+    zs = [np.load(os.path.join(tmp_path, "echo_rank%d.npz" % r)) for r in range(world)]
+    for r, z in enumerate(zs):
+        assert "reachability check failed" in str(z["outcome"]), (r, str(z["outcome"]))
+        assert z["comm"].tolist() == [0, 1] and bool(z["ok"]) and int(z["left"]) == 0
+    assert "timed out" in str(zs[0]["outcome"]) and "stayed away" in str(zs[1]["outcome"])
+
+
+def test_bench_gpus_2_typed_without_a_launcher(capsys):
+    """`python bench.py --gpus N` exactly as typed (no torch.distributed.run) must run the N-rank job: the
+    command becomes the launcher, its ranks are child processes.  Rehearsed with 2 ranks on this box's one GPU
+    (BH_BENCH_REHEARSAL=1: both ranks on device 0, peer-buffer transport; the numbers are not a measurement)."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BH_RCCL_LIB", "BH_COMM")}
+    env["BH_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["replicas_bitwise_identical"] is True
+    assert line["metric"].startswith("PCG subproblems/sec") and "REHEARSAL" in line["data"]
+    assert line["config"]["d_total"] == 2 * 65536 and line["roofline"]["per_rank"][1]["rows"] == 65536
+    with capsys.disabled():
+        print("[bench --gpus 2 as typed, rehearsal] %.1f subproblems/s, %.1f us per subproblem, transport %s"
+              % (line["value"], 1e3 * line["ms_per_step"], line["headline_transport"]))
