@@ -51,13 +51,18 @@ def cpu_share():
         return os.cpu_count() or 1
 
 
-def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS, strong=False):
+MA_CONFIG5 = 64            # BASELINE config 5: 64 linear equalities A = u(4, .) next to the 512 active bounds
+
+
+def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS, strong=False, config=3):
     syn = bh.synthetic
     d_total = d_per_gpu if strong else d_per_gpu * world
     lo, hi = bh.row_shard(d_total, rank, world)
     H = bh.AlHessian.synthetic(hi - lo, n, row0=lo, d_total=d_total, seed=1, colscale=syn.column_scale(n, kind), mu=10.0)
     x, x_l, x_u, fix = syn.box_vectors(n, fix_every=8)
-    cons = bh.MixedConstraints(np.zeros((0, n)), None, fix, l=x_l, u=x_u)
+    mA = MA_CONFIG5 if config == 5 else 0
+    A = syn.splitmix_uniform(4, np.arange(mA * n)).reshape((mA, n), order="F") if mA else np.zeros((0, n))
+    cons = bh.MixedConstraints(A, None, fix, l=x_l, u=x_u)      # reduced projection form: the library factors A_free A_free' itself
     g = H.jtv(syn.residual_rows(lo, hi))            # g = J' r0 (row-sharded J' t + all-reduce)
     w_l, w_u = syn.step_bounds(x, x_l, x_u, fix, syn.initial_tr(g))
     dv = {k: bh.DeviceVector(n, v) for k, v in (("g", g), ("wl", w_l), ("wu", w_u))}
@@ -106,7 +111,7 @@ def host_synthetic_J(R, d, n, kind, chunk=8192):
     return J
 
 
-def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, repeats=5):
+def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, repeats=5, config=3):
     """The oracle timed on the host cores, on the FULL bench workload (the same 65536 x 4096 J, 2 GiB, same vectors recipe):
     whole projected_cg calls, >= `repeats` of them per port, median.  Two ports are timed: the plain-C/OpenMP restatement
     (oracle/benlsip_oracle.c) and the NumPy/OpenBLAS one (the dgemv family Julia's LinearAlgebra dispatches to); `value` is
@@ -118,9 +123,10 @@ def cpu_baseline(kind, kappa2, n_hmul_gpu, n=N_COLS, d_full=D_PER_GPU, repeats=5
     J = host_synthetic_J(R, d_full, n, kind)
     t_gen = time.perf_counter() - t_gen
     inst = R.synthetic_box_vectors(d_full, n, fix_every=8)
-    A = np.zeros((0, n))
+    mA = MA_CONFIG5 if config == 5 else 0
+    A = R.splitmix_uniform(4, np.arange(mA * n)).reshape((mA, n), order="F") if mA else np.zeros((0, n))
     Z = np.zeros((0, n))
-    cons = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
+    cons = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), inst.fixvars, l=inst.x_l, u=inst.x_u)   # the reference's augmented factor
     g = J.T @ inst.r0
     w_l, w_u = R.build_step_bounds(inst.x, cons, R.initial_tr(g))
 
@@ -202,7 +208,7 @@ def self_launch(n_ranks, argv, script=None):
 
     def relay(r, stream, is_out):
         for ln in stream:
-            if is_out and r == 0:
+            if is_out and r == 0 and ln.lstrip().startswith("{"):      # the JSON line; library chatter on stdout ("[Gloo] Rank 0 is connected ...") goes to stderr
                 sys.stdout.write(ln)
                 sys.stdout.flush()
             else:
@@ -244,6 +250,10 @@ def main():
                     help="weak: 65536 rows per GPU (default); strong: the 65536 rows of config 3 split over the GPUs")
     ap.add_argument("--variant", choices=["wc", "ic"], default="wc",
                     help="wc: well-conditioned J (a handful of CG iterations); ic: columns scaled 10^(-3j/n) (hundreds)")
+    ap.add_argument("--config", type=int, choices=[3, 5], default=3,
+                    help="BASELINE config: 3 = box bounds (the headline), 5 = the same J with 64 linear equalities (projection kernel path)")
+    ap.add_argument("--preheat", type=int, default=40,
+                    help="untimed subproblems run before the W warm-up steps to bring the device back to its steady clocks after the host-side set-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-ic-extra", action="store_true",
@@ -343,7 +353,7 @@ def main():
 
     kind = 0 if args.variant == "wc" else 1
     kappa2 = 0.1
-    H, cons, dv, host = setup_instance(bh, rank, world, kind, strong=strong)
+    H, cons, dv, host = setup_instance(bh, rank, world, kind, strong=strong, config=args.config)
 
     def timed_run(steps, warmup):
         """(elapsed max over ranks, (status, iters, n_hmul), stats, error).  A library error on ANY rank (e.g. a peer exchange
@@ -375,7 +385,14 @@ def main():
     # 16 subproblems) is reported next to it as roofline.dense_sample.
     st_probe = run_steps(bh, H, cons, dv, kappa2, 1)
     timed_stride = 4 if args.steps * st_probe[2] <= 64 else 8
+    timed_stride = int(os.environ.get("BH_BENCH_EV_STRIDE", timed_stride))
     bh.set_option("profile_stride", timed_stride)
+    # Preheat (untimed, before the W warm-up steps, all ranks alike): the device idles for seconds while the instance is set up
+    # on the host and then needs ~15-20 ms of work to be back at its steady clocks — the first ~25 subproblems after the set-up
+    # run 3-6 % slower (662, 657, 656, 648, ... -> 624 us: tools/scratch/bracket_cost.py).  With W = 5 the K timed steps would sit
+    # inside that ramp; the preheat is reported in the line ("preheat_steps") and changes nothing inside the timed region.
+    if args.preheat > 0:
+        run_steps(bh, H, cons, dv, kappa2, args.preheat)
     elapsed, out, st, run_err = timed_run(args.steps, args.warmup)
     if run_err is not None:                         # every rank sees the same verdict (gathered), so all of them stop here
         raise SystemExit("bench: the timed run failed: %s" % run_err)
@@ -456,13 +473,15 @@ def main():
         "metric": "PCG subproblems/sec + achieved HBM GB/s, dense m=65536 n=4096 fp64",     # BASELINE.json's metric, verbatim
         "value": args.steps / elapsed,
         "unit": "PCG subproblems/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_steps": args.preheat, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL on one GPU (all ranks share device 0): not a measurement",
         "config": {
-            "workload": "BASELINE config 3%s: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), box bounds, "
+            "workload": "BASELINE config %d%s: synthetic dense NLS, J %d x %d fp64 (%d rows per GPU, row-sharded), %s, "
                         "p=512 active, mu=10, kappa2=0.1, variant=%s; one step = one projected_cg subproblem (bh_pcg_dev), "
-                        "vectors resident in HBM" % (" (rows split over the GPUs)" if strong else " per GPU", host["d_total"], N_COLS, rows_per_gpu, args.variant),
+                        "vectors resident in HBM" % (args.config, " (rows split over the GPUs)" if strong else " per GPU", host["d_total"], N_COLS, rows_per_gpu,
+                                                     "box bounds" if args.config == 3 else "box bounds + %d linear equalities A = u(4,.) (reduced projection form)" % MA_CONFIG5,
+                                                     args.variant),
             "unit_definition": "value counts one unit per projected_cg subproblem of the whole job (all ranks work on the same subproblem); "
                                "under weak scaling the subproblem grows with N (N*65536 rows): shard_units_per_s = N * value",
             "d_total": host["d_total"], "n": N_COLS, "rows_per_gpu": rows_per_gpu,
@@ -563,7 +582,7 @@ def main():
         # steady-state CG iteration cost on the ill-conditioned variant (23 iterations per subproblem): outside the timed region
         # (the first handle stays allocated: freeing 2 GiB here makes the driver scrub it in the background, which took
         # ~5 % of the HBM bandwidth from the next ~60 ms of kernels — tools/ic_transient.py)
-        H2, cons2, dv2, _ = setup_instance(bh, rank, world, 1)
+        H2, cons2, dv2, _ = setup_instance(bh, rank, world, 1, config=args.config)
         run_steps(bh, H2, cons2, dv2, kappa2, 3)
         barrier()
         t1 = time.perf_counter()
@@ -575,7 +594,7 @@ def main():
                               "subproblems_per_s": 1.0 / el2,
                               "cg_iteration_gbs": st["bytes_per_hmul"] / (el2 / max(nh2, 1)) / 1e9}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(kind, kappa2, n_hmul)
+        line["cpu_baseline"] = cpu_baseline(kind, kappa2, n_hmul, config=args.config)
     elif rank == 0:
         line["cpu_baseline"] = None
     if rank == 0:

@@ -390,7 +390,9 @@ struct bh_proj {
     double* M = nullptr;           // mA x mA: A_free A_free' (lower triangle), kept for rank-one downdates (bh_cauchy_step)
     double* Lr = nullptr;          // mA x mA + mA: chol(M) and its reciprocal diagonal (reduced form)
     int* info = nullptr;           // device flag of the Cholesky kernels (= counts + 4)
-    double* tpart = nullptr;       // (ldA/32 + 1) x mA: per-workgroup partials of A_free r (four-kernel CG iteration)
+    double* tpart = nullptr;       // (ldA/32 + 1) x mA: per-workgroup partials of A_free r (three- / four-kernel CG iteration)
+    double* W = nullptr;           // 2 x 64 x 64: [Linv | Linv'] of the reduced factor, mA <= 64 (tri_inv_small_kernel)
+    bool linv_valid = false;       // W belongs to the current Lr
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
     bool M_valid = false;          // M = A_free A_free' for the CURRENT active set (false after factor-only downdates)
     std::vector<uint64_t> last_chunks;   // fixvars of the last successful bh_proj_set_active (reduced form: skip identical pushes)
@@ -1047,6 +1049,7 @@ int32_t ensure_reduced_buffers(bh_proj* P) {
     if (!P->Lr) BH_TRY(dev_alloc(&P->Lr, mA * mA + mA));
     if (!P->info) P->info = P->counts + 4;      // (rides to the host with the AU_* counts: one copy by the mailbox's sealing thread)
     if (!P->tpart) BH_TRY(dev_alloc(&P->tpart, (P->ldA / 32 + 1) * std::max<int64_t>(mA, 1)));
+    if (!P->W && mA <= 64) BH_TRY(dev_alloc(&P->W, 2 * 64 * 64));
     return BH_OK;
 }
 
@@ -1056,6 +1059,7 @@ int32_t ensure_reduced_buffers(bh_proj* P) {
 int32_t launch_chol(bh_proj* P, const CgState* gate) {
     const int mA = (int)P->mA;
     hipStream_t s = g_ctx.stream;
+    P->linv_valid = false;
     if (mA <= 64) {
         hipLaunchKernelGGL(chol_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->M, (int64_t)mA, P->Lr, (int64_t)mA, mA,
                            P->Lr + (int64_t)mA * mA, P->info, 0, gate == nullptr ? 1 : 0, gate);
@@ -1979,7 +1983,7 @@ int32_t bh_proj_destroy(bh_proj* P) {
     if (!P) return BH_OK;
     if (g_ctx.init) (void)hipStreamSynchronize(g_ctx.stream);
     dev_free(P->Ad); dev_free(P->fixrank); dev_free(P->fixidx); dev_free(P->L); dev_free(P->tw); dev_free(P->rpad); dev_free(P->vtmp);
-    dev_free(P->Lr); dev_free(P->M);            // (P->info points into P->counts)
+    dev_free(P->Lr); dev_free(P->M); dev_free(P->W);            // (P->info points into P->counts)
     dev_free(P->newidx); dev_free(P->counts); dev_free(P->chunks_dev); dev_free(P->tpart);
     delete P;
     return BH_OK;
@@ -2092,7 +2096,11 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // and left_mul_tr forming v = P(r) with its partials of r.v.
     // (opt-in, cg_fused = 2: measured at config 5 it buys 0-2 % — the 64-step triangular solve and the single-workgroup kernels
     // around it stay latency-bound — and it changes pHp's rounding like the box form does)
-    const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 2 && P->reduced && P->mA <= 64 && P->tpart != nullptr;
+    // Default (cg_fused = 1): THREE kernels — the triangular solves are replaced by two 64-term dot products per entry with the
+    // explicit inverse of the factor (tri_inv_small_kernel, rebuilt only when the factor changed), which every workgroup of the
+    // kernel that forms v = P(r) repeats for itself: H*p, reduce/update, project (proj_apply_linv_kernel).
+    const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 1 && P->reduced && P->mA <= 64 && P->tpart != nullptr && P->ldA == H->ld;
+    const bool gen_linv = fuse_gen && g_ctx.opt_cg_fused == 1 && P->W != nullptr;
     // Several ranks: the two-kernel form carries the exchange inside the update kernel when the peer-buffer transport is the
     // active one (cg_reduce_update_kernel<false, true>: push the workgroup's 32 columns + its rank's share of pHp, wait, sum in
     // rank order); an RCCL all-reduce cannot sit inside a kernel, so that path keeps the three-kernel form.
@@ -2101,19 +2109,32 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         (gp == c.g || n == n_pad)) {
         BH_TRY(hess_ready(H));
         if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
-        if (fuse_gen) {
-            // :702-718 by the init kernels: r = g, w = 0, v = P(r), rtv, p_1 = -v (in c.p), tol_cg, CgState (stop_at = 0)
-            hipLaunchKernelGGL((cg_init_kernel<false>), dim3(1), dim3(CG_T), 0, s, a);
-            BH_TRY(launch_project(P, c.r, c.v, c.d_state));
-            hipLaunchKernelGGL(cg_init_finish_kernel, dim3(1), dim3(CG_T), 0, s, a);
-        }
         const int64_t nrows = H->d + H->q_eff;
         const int grid = grid_for(rs_cfg, nrows);
         const int nblk = (H->nchunks + 15) / 16;
         double* pbuf[2] = {c.p, c.p2};
         double* rvbuf[2] = {c.rvpart, c.rvpart + n_pad / 2};
-        const int nch_v = ((int)n + 1) / 2;
-        const int nrv = fuse_gen ? (nch_v + 63) / 64 : nblk;            // who writes the r.v partials: left_mul_tr (64 chunks per workgroup) or the update kernel
+        const int nch_v = gen_linv ? H->nchunks : ((int)n + 1) / 2;    // proj_apply_linv_kernel also keeps the padding of v at zero
+        const int nrv = fuse_gen ? (nch_v + 63) / 64 : nblk;            // who writes the r.v partials: the projection kernel (64 chunks per workgroup) or the update kernel
+        const int vv_off = (int)(n_pad / 4);                            // v.v partials of the init launch, behind the r.v partials (nrv <= n_pad / 128)
+        if (gen_linv) {
+            if (!P->linv_valid) {
+                hipLaunchKernelGGL(tri_inv_small_kernel, dim3(1), dim3(256), 0, s, (const double*)P->Lr, (int)P->mA, P->W);
+                P->linv_valid = true;
+            }
+            // :705-710 in two launches: tw = A_free mask(g); v = P(g), p_1 = -v and the partials of r.v, v.v.  r = g and w = 0 are
+            // formed by the first update kernel, CgState is set by workgroup 0 of the first H*p launch (init_done = 2).
+            ProjArgs pa = proj_args(P, nullptr, true);
+            hipLaunchKernelGGL(proj_left_mul_kernel, dim3((unsigned)P->mA), dim3(256), 0, s, pa, gp);
+            pa.tpart = P->tw; pa.tpart_nblk = 1; pa.rvpart = rvbuf[0]; pa.vvpart = rvbuf[0] + vv_off; pa.p_out = c.p;
+            pa.W = P->W; pa.nch_pad = H->nchunks; pa.fused_j = 0;
+            hipLaunchKernelGGL((proj_apply_linv_kernel<true>), dim3((unsigned)nrv), dim3(256), 0, s, pa, gp, c.v);
+        } else if (fuse_gen) {
+            // :702-718 by the init kernels: r = g, w = 0, v = P(r), rtv, p_1 = -v (in c.p), tol_cg, CgState (stop_at = 0)
+            hipLaunchKernelGGL((cg_init_kernel<false>), dim3(1), dim3(CG_T), 0, s, a);
+            BH_TRY(launch_project(P, c.r, c.v, c.d_state));
+            hipLaunchKernelGGL(cg_init_finish_kernel, dim3(1), dim3(CG_T), 0, s, a);
+        }
         int expect_stop_at = H->last_n_hmul > 0 ? H->last_n_hmul + 1 : 0;     // the launch expected to find the loop finished
         auto launch_stream = [&](int j) -> int32_t {            // H*p of iteration j (1-based), p_j formed on the fly
             RowStreamArgs ra = rs_args(H, nrows, nullptr);
@@ -2121,7 +2142,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             if (fuse_gen) { ra.v = c.p; ra.negate = 0; }                            // used by j == 1 only: p_1 = -P(g), formed by the init kernels
             else { ra.v = gp; ra.negate = 1; ra.negmask = a.fixrank; }             //                      p_1 = -mask(g), formed on the fly
             CgFuse& f = ra.cf;
-            f.st = c.d_state; f.j = j; f.n = (int)n; f.max_iter = max_iter; f.init_done = fuse_gen ? 1 : 0;
+            f.st = c.d_state; f.j = j; f.n = (int)n; f.max_iter = max_iter; f.init_done = gen_linv ? 2 : fuse_gen ? 1 : 0; f.vv_off = vv_off;
             f.vvec = c.v; f.p_old = pbuf[(j - 1) & 1]; f.p_new = pbuf[j & 1];
             f.rvpart = rvbuf[(j - 1) & 1]; f.nrv = nrv;
             f.w = wp; f.wl = wlp; f.wu = wup;
@@ -2129,10 +2150,11 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             f.kappa2 = kappa2; f.atol_f2b = atol_f2b;
             f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
             int slot = -1;
+            const bool expect_stop = j == expect_stop_at || j > max_iter || (expect_stop_at == 0 && j > 1);
             BH_TRY(profile_begin(H, j - 1, &slot));
             // a handle without history cannot predict its exit: its look-ahead launches (j > 1) take the no-prefetch symbol too, so
             // that launches which stop in their prologue never show up under the streaming kernel's name in a profile
-            launch_row_stream_cgp(rs_cfg, ra, grid, s, j == expect_stop_at || j > max_iter || (expect_stop_at == 0 && j > 1));
+            launch_row_stream_cgp(rs_cfg, ra, grid, s, expect_stop);
             if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], s));
             return BH_OK;
         };
@@ -2150,11 +2172,16 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
                 hipLaunchKernelGGL((cg_reduce_update_kernel<false, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
                 return;
             }
-            u.A = P->Ad; u.ldA = P->ldA; u.mA = (int)P->mA; u.tpart = P->tpart; u.init_in_memory = 1;
+            u.A = P->Ad; u.ldA = P->ldA; u.mA = (int)P->mA; u.tpart = P->tpart; u.init_in_memory = gen_linv ? 0 : 1;
             hipLaunchKernelGGL((cg_reduce_update_kernel<true, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
             // y = (A_free A_free')^{-1} (A_free r): partial sums + the two triangular solves; then v = r_free - A_free'y and r.v
             ProjArgs pa = proj_args(P, c.d_state, true);
             pa.tpart = P->tpart; pa.tpart_nblk = nblk; pa.rvpart = rvbuf[j & 1]; pa.fused_j = j;
+            if (gen_linv) {
+                pa.W = P->W; pa.nch_pad = H->nchunks;
+                hipLaunchKernelGGL((proj_apply_linv_kernel<false>), dim3((unsigned)nrv), dim3(256), 0, s, pa, (const double*)c.r, c.v);
+                return;
+            }
             hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
             hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 4>), dim3((nch_v + 63) / 64), dim3(256), 0, s, pa, (const double*)c.r, c.v);
         };
@@ -2795,6 +2822,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
             if (g_ctx.opt_chol_downdate) {
                 P->M_valid = false;     // only the factor follows the active set on this path
                 // add_active!: one more fixed variable = rank-one downdate of chol(A_free A_free'), O(mA^2)
+                P->linv_valid = false;
                 if (mA <= 64)
                     hipLaunchKernelGGL(chol_downdate_small_kernel, dim3(1), dim3(64), 0, s, P->Lr, (const double*)P->Ad, P->ldA, mA, P->info,
                                        (const CgState*)c.d_state);

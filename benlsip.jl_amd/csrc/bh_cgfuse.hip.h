@@ -94,6 +94,14 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
     const int cc = min(c, a.nchunks - 1);                      // out-of-range threads load a valid chunk and drop the result:
     SlabBatch sb;                                              // no branch around the loads (see LaneBatch::issue)
     sb.issue(P2, ld2, cc, rl, a.G);
+    // GEN: this thread's entries of A for the partials of A_free r below (rows rl, rl + 16, ...; up to 64 rows), asked for now
+    double2 arow[4];
+    if (GEN) {
+        const double2* A2 = reinterpret_cast<const double2*>(a.A);
+        const int64_t ldA2 = a.ldA >> 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) arow[k] = A2[(int64_t)min(rl + 16 * k, a.mA - 1) * ldA2 + cc];
+    }
     if (upd && a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[c];   // last: its compare is scheduled next to it
 
     // ---- this workgroup's 32 columns of Hp = sum of the slabs (fixed order) --------------------------------------------
@@ -236,16 +244,14 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
         __syncthreads();
         if (cont) {
             const double2 rm = rsm[cl];
-            const int64_t ldA2 = a.ldA >> 1;
-            const double2* A2 = reinterpret_cast<const double2*>(a.A);
-            for (int i = rl; i < a.mA; i += 16) {
-                double prod = 0.0;
-                if (valid) {
-                    const double2 av = A2[(int64_t)i * ldA2 + c];
-                    prod = fma(av.y, rm.y, av.x * rm.x);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = rl + 16 * k;
+                if (i < a.mA) {                                   // (uniform per 16-lane row)
+                    double prod = valid ? fma(arow[k].y, rm.y, arow[k].x * rm.x) : 0.0;
+                    prod = row16_sum(prod);
+                    if (cl == 0) a.tpart[(int64_t)blockIdx.x * a.mA + i] = prod;
                 }
-                prod = row16_sum(prod);
-                if (cl == 0) a.tpart[(int64_t)blockIdx.x * a.mA + i] = prod;
             }
         }
     }

@@ -22,7 +22,9 @@ enum { MODE_JV = 0, MODE_JTV = 1, MODE_FUSED = 2 };
 struct CgFuse {
     CgState* st;
     int j;                  // iteration of this launch, 1-based (the reference's `iter` while the H*p of :722 runs)
-    int init_done;          // general constraints: :702-718 was done by the init kernels (p_1 = -P(g) is in memory, CgState is set)
+    int init_done;          // general constraints: 1 = :702-718 was done by the init kernels (p_1 = -P(g) is in memory, CgState is set);
+                            // 2 = v, p_1 and the partials of r.v / v.v are in memory, workgroup 0 of launch 1 sets CgState from them
+    int vv_off;             // init_done == 2: the v.v partials follow the r.v partials at this offset
     int n, max_iter;
     const double* vvec;     // v = P(r) after iteration j-1                (j >= 2)
     const double* p_old;    // p_{j-1}                                     (j >= 2)
@@ -215,20 +217,28 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
         if (f.j == 1) {
             // projected_cg's initialisation (:702-718) belongs to workgroup 0: r = g, v = P(r) = mask(g), p = -v (formed above),
             // rtv = r.v, tol_cg = kappa2*||v||, iter = 1, all flags down
-            if (blockIdx.x == 0 && !f.init_done) {
-                double rtv0 = 0.0;
+            if (blockIdx.x == 0 && f.init_done != 1) {
+                double t = 0.0, vsq = 0.0;
+                if (f.init_done == 2) {
+                    // general constraints, three-kernel iteration: v = P(g), p_1 = -v are in memory (proj_apply_linv_kernel<INIT>),
+                    // which also left the partials of r.v and of v.v (every wave gets the same sums)
+                    t = wave_fixed_sum(f.rvpart, f.nrv);
+                    vsq = wave_fixed_sum(f.rvpart + f.vv_off, f.nrv);
+                } else {
+                    double rtv0 = 0.0;
 #pragma unroll
-                for (int k = 0; k < CPT; ++k) {        // vv = -mask(g):  r.v = v.v = sum of squares of the free components
-                    rtv0 = fma(vv[k].x, vv[k].x, rtv0); rtv0 = fma(vv[k].y, vv[k].y, rtv0);
-                }
-                rtv0 = wave_sum(rtv0);
-                if (lane == 0) pro[0][wave] = rtv0;
-                __syncthreads();
-                if (tid == 0) {
-                    double t = 0.0;
+                    for (int k = 0; k < CPT; ++k) {        // vv = -mask(g):  r.v = v.v = sum of squares of the free components
+                        rtv0 = fma(vv[k].x, vv[k].x, rtv0); rtv0 = fma(vv[k].y, vv[k].y, rtv0);
+                    }
+                    rtv0 = wave_sum(rtv0);
+                    if (lane == 0) pro[0][wave] = rtv0;
+                    __syncthreads();
                     for (int w2 = 0; w2 < NW; ++w2) t += pro[0][w2];
-                    st->rtv = t;                                   // :707  (r.v with v = mask(r))
-                    st->tol_cg = f.kappa2 * sqrt(t);               // :710
+                    vsq = t;
+                }
+                if (tid == 0) {
+                    st->rtv = t;                                   // :707  (r.v; box: v = mask(r))
+                    st->tol_cg = f.kappa2 * sqrt(vsq);             // :710
                     st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
                     st->iter = 1; st->max_iter = f.max_iter;
                     st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "bh_reduce.hip.h"
 #include "bh_cg.hip.h"
 
@@ -26,6 +27,11 @@ struct ProjArgs {
     int tpart_nblk;
     double* rvpart;         // proj_left_mul_tr_kernel: this workgroup's partial of r.v
     int fused_j;            // > 0: launch of iteration fused_j — skipped iff the loop stopped at or before it (CgState::stop_at)
+    // three-kernel general-constraint CG iteration (proj_apply_linv_kernel):
+    const double* W;        // [Linv | Linv'] of tri_inv_small_kernel (2 x 64 x 64, zero outside the triangle and beyond mA)
+    double* vvpart;         // INIT: this workgroup's partial of v.v (tol_cg = kappa2*||v||, :710)
+    double* p_out;          // INIT: p_1 = -v (:708)
+    int nch_pad;            // chunks per padded vector (ld / 2): the kernel keeps [n, ld) of its outputs at zero
 };
 
 __device__ __forceinline__ bool proj_skip(const CgState* st) { return st != nullptr && (st->done || !st->need_proj); }
@@ -641,6 +647,192 @@ __global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
         if (lane < j) xi = fma(-lji, xj, xi);
     }
     if (lane < m) a.tw[lane] = xi;
+}
+
+// Explicit inverse of the reduced-form factor, m <= 64:  W[0 .. 4096) = Linv column-major (W[k*64 + i] = Linv[i][k]),
+// W[4096 .. 8192) = Linv' column-major (W[4096 + i*64 + k] = Linv[i][k]); zero above the diagonal and beyond m.  With it
+// y = (A_free A_free')^{-1} t = Linv'(Linv t) is two 64-term dot products per entry that EVERY workgroup of the kernel consuming
+// y can afford to repeat — the single-workgroup, 128-step dependent triangular solve (trsv_small_kernel, 8.6 us per CG
+// iteration) leaves the loop.  Built only when the factor has changed since the last projected_cg that wanted it.
+// One workgroup of 256 threads, everything in LDS, by block recursion on  inv([A 0; B C]) = [Ai 0; -Ci B Ai  Ci]:
+//   level 1  the four 16 x 16 diagonal blocks, one column per lane (16 lanes of each wave), substitution fully unrolled in registers;
+//   level 2  two merges to 32 x 32 (two 16^3 products each), level 3 one merge to 64 x 64 (two 32^3 products): every thread
+//            owns fixed entries of the product and accumulates them in index order (bit-reproducible).
+// (History: lane = row with v_readlane broadcasts, 16 columns per wave in registers — 36 us: 64 steps x 16 columns of
+// readlane + fma per wave, instruction-issue bound.)  m < 64 is padded with the identity.
+__global__ __launch_bounds__(256) void tri_inv_small_kernel(const double* __restrict__ L, int m, double* __restrict__ W) {
+    __shared__ double Ls[64][65], Xs[64][65], Ts[32][33], ds[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < 4096; e += 256) {
+        const int i = e & 63, k = e >> 6;
+        Ls[i][k] = (i < m && k <= i) ? L[i + (int64_t)k * m] : (i == k ? 1.0 : 0.0);
+        Xs[i][k] = 0.0;
+    }
+    if (tid < 64) ds[tid] = (tid < m) ? L[(int64_t)m * m + tid] : 1.0;          // reciprocal diagonal (chol_small_kernel)
+    __syncthreads();
+    if (lane < 16) {                                                             // level 1: block `wave`, column `lane` of it
+        const int base = 16 * wave;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double acc = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < i; ++l) acc = fma(-Ls[base + i][base + l], x[l], acc);
+            x[i] = acc * ds[base + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Xs[base + i][base + lane] = x[i];
+    }
+    __syncthreads();
+    // merge<H>(base, t): X21 = -X22 (L21 X11) for the diagonal blocks [base, base+H) and [base+H, base+2H).  8 H threads per
+    // merge: thread t owns column c = t % H and the H/8 rows r0, r0 + 8, ... of it (independent accumulators; the sums run
+    // over the whole block — the zeros above the diagonals of X11 and X22 add nothing — so the loops have fixed trip counts).
+    auto merge = [&](auto Htag, const int base, const int t, const int trow0) {
+        constexpr int H = decltype(Htag)::value, NR = H / 8;
+        const int R0 = base + H, C0 = base, c = t % H, r0 = t / H;
+        double acc[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[q] = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < H; ++l) {                                            // T = L21 X11
+            const double x = Xs[C0 + l][C0 + c];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[q] = fma(Ls[R0 + r0 + 8 * q][C0 + l], x, acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) Ts[trow0 + r0 + 8 * q][c] = acc[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[q] = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < H; ++l) {                                            // X21 = -X22 T
+            const double tv = Ts[trow0 + l][c];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[q] = fma(Xs[R0 + r0 + 8 * q][R0 + l], tv, acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < NR; ++q) Xs[R0 + r0 + 8 * q][C0 + c] = -acc[q];
+        __syncthreads();
+    };
+    merge(std::integral_constant<int, 16>(), 32 * (tid >> 7), tid & 127, 16 * (tid >> 7));   // level 2: two merges side by side
+    merge(std::integral_constant<int, 32>(), 0, tid, 0);                                       // level 3
+    for (int e = tid; e < 4096; e += 256) {
+        const int i = e & 63, k = e >> 6;
+        W[k * 64 + i] = (i < m && k < m) ? Xs[i][k] : 0.0;                       // Linv, column-major
+    }
+    for (int e = tid; e < 4096; e += 256) {
+        const int k = e & 63, i = e >> 6;
+        W[4096 + i * 64 + k] = (i < m && k < m) ? Xs[i][k] : 0.0;                // Linv', column-major
+    }
+}
+
+// Third kernel of the three-kernel general-constraint CG iteration (reduced projection form, mA <= 64):
+//   t = sum of the per-workgroup partials of A_free r that cg_reduce_update_kernel<GEN> left        (left_mul, poly:86-98)
+//   y = Linv'(Linv t)                                                                               (the two solves, poly:132-133)
+//   v = r_free - A_free' y on the free variables, 0 on the fixed ones; this workgroup's partial of r.v   (poly:134, :743)
+// Every workgroup forms t and y itself (same operands, same order: same bits everywhere), then its 64 chunks of v.
+// Block = 64 chunks x 4 row groups (as proj_left_mul_tr_kernel<true, 4>); grid = ceil(nch_pad / 64).
+// INIT (before the first H*p, :705-710): r = g_minor, tpart = the one "partial" proj_left_mul_kernel wrote; also stores
+// p_1 = -v and the partials of v.v.
+template <bool INIT>
+__global__ __launch_bounds__(256) void proj_apply_linv_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
+    if (!INIT && a.state->stop_at != 0 && a.fused_j >= a.state->stop_at) return;
+    __shared__ double tq[4][64];
+    __shared__ double ts[64], us[64], ys[64];
+    __shared__ double2 sm[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6, m = a.mA;
+    const int c = blockIdx.x * 64 + cl;
+    const int cc = min(c, a.nch_pad - 1);
+    // ---- every load first; the partials of A_free r lead (they are consumed first and loads return in order) ------------------
+    // right-hand side: wave q folds a quarter of the partial blocks, in order; 32 loads in flight per batch (all of them at
+    // n = 4096: 128 blocks), clamped indices so that no branch stands between the loads
+    const int per = (a.tpart_nblk + 3) / 4;
+    const int b0 = rg * per, b1 = min(a.tpart_nblk, b0 + per);
+    const int col = min(cl, m - 1);
+    double x0[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) x0[k] = a.tpart[(int64_t)max(min(b0 + k, b1 - 1), 0) * m + col];
+    double w1[16], w2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        w1[k] = a.W[(16 * rg + k) * 64 + cl];               // Linv[cl][16 rg + k]
+        w2[k] = a.W[4096 + (16 * rg + k) * 64 + cl];        // Linv[16 rg + k][cl]
+    }
+    const double2* A2 = reinterpret_cast<const double2*>(a.A);
+    const int64_t ld2 = a.ldA >> 1;
+    double2 av[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) av[k] = A2[(int64_t)min(rg + 4 * k, m - 1) * ld2 + cc];
+    const double2 rk = reinterpret_cast<const double2*>(r)[cc];
+    int2 fr = make_int2(-1, -1);
+    if (a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[cc];
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (b0 + k < b1) acc += x0[k];
+        for (int b = b0 + 32; b < b1; b += 32) {            // more than 128 partial blocks (n > 4096)
+            double x[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) x[k] = a.tpart[(int64_t)min(b + k, b1 - 1) * m + col];
+#pragma unroll
+            for (int k = 0; k < 32; ++k)
+                if (b + k < b1) acc += x[k];
+        }
+        tq[rg][cl] = (cl < m) ? acc : 0.0;
+    }
+    __syncthreads();
+    if (rg == 0) ts[cl] = (tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl]);
+    __syncthreads();
+    // ---- u = Linv t -------------------------------------------------------------------------------------------------------------
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fma(w1[k], ts[16 * rg + k], acc);
+    tq[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0) us[cl] = (tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl]);
+    __syncthreads();
+    // ---- y = Linv' u ------------------------------------------------------------------------------------------------------------
+    acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fma(w2[k], us[16 * rg + k], acc);
+    tq[rg][cl] = acc;
+    __syncthreads();
+    if (rg == 0) ys[cl] = (tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl]);
+    __syncthreads();
+    // ---- left_mul_tr on this workgroup's chunks (rows rg, rg + 4, ...: the order of proj_left_mul_tr_kernel<true, 4>) -------------
+    double2 z = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = rg + 4 * k;
+        if (i < m) {
+            const double yi = ys[i];
+            z.x = fma(yi, av[k].x, z.x);
+            z.y = fma(yi, av[k].y, z.y);
+        }
+    }
+    sm[rg][cl] = z;
+    __syncthreads();
+    if (rg != 0) return;
+    const double tx = (sm[0][cl].x + sm[1][cl].x) + (sm[2][cl].x + sm[3][cl].x);
+    const double ty = (sm[0][cl].y + sm[1][cl].y) + (sm[2][cl].y + sm[3][cl].y);
+    double rv = 0.0, vv = 0.0;
+    if (c < a.nch_pad) {
+        const int j0 = 2 * c, j1 = 2 * c + 1;
+        const double v0 = (fr.x >= 0 || j0 >= a.n) ? 0.0 : rk.x - tx;
+        const double v1 = (fr.y >= 0 || j1 >= a.n) ? 0.0 : rk.y - ty;
+        reinterpret_cast<double2*>(out)[c] = make_double2(v0, v1);
+        if (INIT) reinterpret_cast<double2*>(a.p_out)[c] = make_double2(-v0, -v1);
+        const double r0 = (j0 < a.n) ? rk.x : 0.0, r1 = (j1 < a.n) ? rk.y : 0.0;
+        rv = fma(r1, v1, r0 * v0);
+        vv = fma(v1, v1, v0 * v0);
+    }
+    rv = wave_sum(rv);
+    if (INIT) vv = wave_sum(vv);
+    if (cl == 0) {
+        a.rvpart[blockIdx.x] = rv;
+        if (INIT) a.vvpart[blockIdx.x] = vv;
+    }
 }
 
 // tw <- L' \ (L \ tw)   (:114-115, :132-133).  Single workgroup, 64-wide blocked substitution.

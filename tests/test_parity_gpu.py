@@ -948,7 +948,9 @@ def test_pcg_config3_full_size_against_oracle(bh):
     cons5_o = R.make_mixed_constraints(A5, R.chol_lower(A5 @ A5.T), inst.fixvars, l=inst.x_l, u=inst.x_u)
     w_ref, s_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons5_o, 0.01)
     lib = bh._lib.lib()
-    for form, fused in ((1, 1), (0, 1), (1, 2)):           # reduced, augmented, reduced with the four-kernel iteration
+    # reduced form with the three-kernel iteration (default), augmented form (seven kernels), reduced form with the four-kernel
+    # iteration (triangular solves in their own launch), reduced form with seven kernels
+    for form, fused in ((1, 1), (0, 1), (1, 2), (1, 0)):
         lib.bh_set_option(b"proj_form", form)
         lib.bh_set_option(b"cg_fused", fused)
         cons5 = bh.MixedConstraints(A5, cons5_o.chol_L, inst.fixvars, l=inst.x_l, u=inst.x_u)
@@ -956,6 +958,8 @@ def test_pcg_config3_full_size_against_oracle(bh):
         lib.bh_set_option(b"proj_form", 1)
         lib.bh_set_option(b"cg_fused", 1)
         assert int(status) == int(s_ref) and info["iters"] == it_ref, (form, int(status), int(s_ref), info["iters"], it_ref)
+        print("[config 5 full size] proj_form=%d cg_fused=%d: %d iterations, |w - w_oracle|/|w_oracle| = %.2e (bound 1e-8)"
+              % (form, fused, info["iters"], relnorm(w, w_ref)))
         assert relnorm(w, w_ref) <= 1e-8, (form, relnorm(w, w_ref))
         assert np.linalg.norm(A5 @ w) <= 1e-10 * np.linalg.norm(A5) * np.linalg.norm(w)
         # fixed components: exact zeros in the reduced form; rounding-level in the augmented form, as in the reference
