@@ -375,6 +375,7 @@ struct bh_hess {
     std::vector<int> ev_pending;   // launch index (within the running bh_pcg) of each recorded pair
     uint64_t hmul_seq = 0;         // H*p launches of bh_pcg calls on this handle (profile sampling)
     bool counted = false;          // included in g_ctx.live_hess (false while a create is failing)
+    bool pending_finish = false;   // bh_hess_create_async on a rank without rows: the d_total collective runs at wait / first use, as on its peers
 };
 
 struct bh_proj {
@@ -739,6 +740,7 @@ static void async_upload_worker(bh_hess* H, const double* J, int64_t d, int64_t 
 
 // Every entry point that reads the image calls this first: joins a pending asynchronous upload (bh_hess_wait does the same).
 int32_t hess_ready(bh_hess* H) {
+    if (H && !H->up && H->pending_finish) { H->pending_finish = false; return finish_hess_create(H); }
     if (!H || !H->up) return BH_OK;
     AsyncUpload* u = H->up;
     if (u->worker.joinable()) u->worker.join();
@@ -1626,8 +1628,8 @@ int32_t bh_hess_create(bh_hess** out, const double* J, int64_t d, int64_t n, int
     if (rc == BH_OK) rc = upload_transposed(J, d, n, ldJ, H->Jd, 0, H->ld);
     if (rc == BH_OK) rc = upload_transposed(C, q, n, ldC, H->Jd, d, H->ld);
     if (rc == BH_OK) rc = finish_hess_create(H);
+    if (rc == BH_OK) rc = sync_flush();
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
-    BH_TRY(sync_flush());
     *out = H;
     H->counted = true;
     g_ctx.live_hess += 1;
@@ -1702,7 +1704,11 @@ int32_t bh_hess_create_async(bh_hess** out, const double* J, int64_t d, int64_t 
             u->worker = std::thread(async_upload_worker, H, J, d, n, ldJ, g_ctx.device);
         }
     } else if (rc == BH_OK) {
-        rc = finish_hess_create(H);
+        // no rows on this rank (d_total < ranks): nothing to upload, but the d_total all-reduce of finish_hess_create must run where
+        // the peers run theirs — at bh_hess_wait / first use — or any collective issued between create and wait (bh_resid_sqnorm,
+        // another handle) would be matched against it
+        if (comm_active()) H->pending_finish = true;
+        else rc = finish_hess_create(H);
     }
     if (rc != BH_OK) { bh_hess_destroy(H); return rc; }
     *out = H;
@@ -2059,7 +2065,6 @@ static int launch_batch_size(const bh_hess* H) {
 // The first batch is sized by the previous call on the handle (consecutive subproblems of a minor loop behave alike):
 // an exact prediction means no gated launches and no host round trip inside the loop at all.
 constexpr int kFirstBatchCap = 32;
-constexpr int kFirstBatchCapRccl = 8;
 
 // Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
 // still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
@@ -2280,9 +2285,11 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // while launch-ahead batches run).  done_by(target) is that rank-independent predicate.
     MirrorWord mw{};
     auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
-    // (an RCCL all-reduce cannot be gated from the device: every over-launched iteration pays for one, so predict less boldly)
-    const int first_cap = (comm_active() && !use_peer_path()) ? kFirstBatchCapRccl : kFirstBatchCap;
-    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, first_cap) : std::min(batch, 2);
+    // (an RCCL all-reduce cannot be gated from the device: every over-launched iteration pays for one.  With history on the handle
+    // the first batch is the previous call's count exactly — the prediction the two-kernel form uses for its stop_at launch — so a
+    // repeated subproblem enqueues as many collectives as it has H*p products; without history it stays small.)
+    const bool rccl_path = comm_active() && !use_peer_path();
+    const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : std::min(batch, rccl_path ? 1 : 2);
     BH_TRY(launch_batch(first));
     BH_TRY(wait_mirror(c, a.tag, launched, &mw));
     if (!done_by(launched) && launched < max_iter) {
@@ -2354,7 +2361,11 @@ static int32_t pcg_impl(bh_hess* H, bh_proj* P, const double* g_minor, const dou
     // Device callers with even n and 16-byte aligned buffers hand over memory the kernels can use in place (16-byte chunk
     // loads stay in bounds); host callers, odd n and unaligned pointers go through the zero-padded workspace.
     auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    const bool in_place = dev && (n % 2 == 0) && aligned16(g_minor) && aligned16(w_l) && aligned16(w_u) && aligned16(w_out);
+    // With a communicator the choice must not depend on this rank's pointers: in place only when n == ld, where the CG iteration
+    // shape chosen in pcg_run (two-kernel / three-kernel, which exchange different payloads and round pHp differently) is the
+    // same whether a rank works in place or through the workspace; below ld every rank stages.
+    const bool in_place = dev && (n % 2 == 0) && aligned16(g_minor) && aligned16(w_l) && aligned16(w_u) && aligned16(w_out) &&
+                          (!comm_active() || n == H->ld);
     const double *gp = g_minor, *wlp = w_l, *wup = w_u;
     double* wp = w_out;
     if (!in_place) {

@@ -65,8 +65,16 @@ def main():
     out["box_mid_w"], out["box_mid_st"], out["box_mid_it"] = w, int(st), info["iters"]
     w, st, info = bh.projected_cg(gm, H, np.where(fix, 0.0, -big), np.where(fix, 0.0, big), box, 1e-3, full_output=True)
     # the same call again: the first batch is now sized by the previous call on this handle
+    ar0 = H.stats()["n_allreduce"]
     w2, st2, info2 = bh.projected_cg(gm, H, np.where(fix, 0.0, -big), np.where(fix, 0.0, big), box, 1e-3, full_output=True)
     out["box_again_same"] = bool(np.array_equal(w, w2) and int(st) == int(st2) and info["iters"] == info2["iters"])
+    # collectives of the repeated call: with the previous call's count as the first batch none is enqueued past the exit
+    # (capped at 32 iterations per batch, so a longer loop over RCCL still over-launches by < one batch)
+    out["box_again_allreduce"], out["box_again_nh"] = H.stats()["n_allreduce"] - ar0, info2["n_hmul"]
+    w3, st3, info3 = bh.projected_cg(gm, H, np.where(fix, 0.0, -big), np.where(fix, 0.0, big), box, 3e-2, full_output=True)
+    ar1 = H.stats()["n_allreduce"]
+    w3, st3, info3 = bh.projected_cg(gm, H, np.where(fix, 0.0, -big), np.where(fix, 0.0, big), box, 3e-2, full_output=True)
+    out["box_mid_again_allreduce"], out["box_mid_again_nh"] = H.stats()["n_allreduce"] - ar1, info3["n_hmul"]
 
     # linear equalities + fixed variables (reduced-form projection on the device)
     gen = bh.MixedConstraints(A, None, fix, l=P["xlow"], u=P["xupp"])

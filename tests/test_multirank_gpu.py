@@ -19,7 +19,7 @@ import uuid
 import numpy as np
 import pytest
 
-from _util import R, assert_rounding_dominated, first_decision_difference, relnorm
+from _util import R, assert_rounding_dominated, first_decision_difference, relnorm, w_tolerance
 
 pytestmark = pytest.mark.gpu
 
@@ -120,6 +120,10 @@ def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     assert model(z["box_tight_w"]) == pytest.approx(model(w), rel=5e-3)      # measured 1.0e-3 with one iteration more
     assert int(z["box_tight_nh"]) > 24           # well past the first launch batch: the launch-ahead decisions were exercised
     assert bool(z["box_again_same"])
+    # a repeated subproblem enqueues exactly one all-reduce per H*p when its count fits the first batch (19 iterations here);
+    # the 78-iteration one stays within one launch-ahead batch of its count
+    assert int(z["box_mid_again_allreduce"]) == int(z["box_mid_again_nh"]), (int(z["box_mid_again_allreduce"]), int(z["box_mid_again_nh"]))
+    assert int(z["box_again_nh"]) <= int(z["box_again_allreduce"]) <= int(z["box_again_nh"]) + 8
 
     gen = R.make_mixed_constraints(A, R.chol_lower(A @ A.T), fix, l=P["xlow"], u=P["xupp"])
     w, st, it = R.projected_cg(gm, Ho, z["wl"], z["wu"], gen, 1e-6)
@@ -285,3 +289,37 @@ def test_bench_gpus_2_typed_without_a_launcher(capsys):
     with capsys.disabled():
         print("[bench --gpus 2 as typed, rehearsal] %.1f subproblems/s, %.1f us per subproblem, transport %s"
               % (line["value"], 1e3 * line["ms_per_step"], line["headline_transport"]))
+
+
+@pytest.mark.parametrize("comm", ["ipc", "staged"])
+def test_advisor_r2_rank_invariant_iteration_shape_and_deferred_row_count(tmp_path, comm):
+    """ADVICE r2 (medium x 2): (a) with a communicator the CG iteration shape is chosen from replicated quantities only — a rank
+    whose device vectors are 8 bytes off 16-byte alignment (n = 40 below ld = 48) must run the same exchange protocol as an
+    aligned one: bit-identical replicas, equal to the unsharded oracle; (b) bh_hess_create_async on a rank without rows defers its
+    d_total all-reduce to bh_hess_wait like its peers, so a collective between create and wait (bh_resid_sqnorm) pairs up."""
+    world = 3
+    run_ranks("advice_worker.py", world, tmp_path, comm, timeout=300)
+    z = [np.load(os.path.join(tmp_path, "advice_rank%d.npz" % r)) for r in range(world)]
+    for r in range(1, world):
+        for key in ("a_w", "a_st", "a_it", "a_nh", "b_sq", "b_hv"):
+            assert np.array_equal(z[0][key], z[r][key]), (r, key)
+    assert all(bool(x["a_same"]) for x in z)
+    rng = np.random.default_rng(21)
+    d, n = 500, 40
+    J = rng.standard_normal((d, n)) / np.sqrt(d) * np.logspace(0, -1, n)
+    g = rng.standard_normal(n)
+    fix = np.zeros(n, dtype=bool)
+    fix[[3, 17, 30]] = True
+    Z = np.zeros((0, n))
+    cons = R.make_mixed_constraints(Z, R.chol_lower(Z @ Z.T), fix, l=-np.ones(n), u=np.ones(n))
+    Ho, wl, wu = R.AlHessian(J, Z, 1.0), np.where(fix, 0.0, -1e3), np.where(fix, 0.0, 1e3)
+    w, st, it = R.projected_cg(g, Ho, wl, wu, cons, 1e-6)
+    assert int(z[0]["a_st"]) == int(st) and int(z[0]["a_it"]) == it and int(z[0]["a_nh"]) >= 5
+    tol = w_tolerance(g, Ho, wl, wu, cons, 1e-6, w)              # 20 x the oracle's own rounding sensitivity (cond(H) ~ 1e2, kappa2 = 1e-6)
+    print("[advisor r2 (a), %s] |w - w_oracle| / |w_oracle| = %.2e, tolerance %.2e" % (comm, relnorm(z[0]["a_w"], w), tol))
+    assert relnorm(z[0]["a_w"], w) <= tol
+    rng = np.random.default_rng(5)
+    J = rng.standard_normal((2, 24)); C = rng.standard_normal((1, 24)); gvec = rng.standard_normal(24); r = rng.standard_normal(2)
+    assert int(z[2]["b_rows"]) == 0
+    assert float(z[0]["b_sq"]) == pytest.approx(float(r @ r), rel=1e-14)
+    assert relnorm(z[0]["b_hv"], R.hmul(R.AlHessian(J, C, 2.0), gvec)) <= 1e-12
