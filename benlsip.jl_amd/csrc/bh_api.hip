@@ -98,10 +98,11 @@ struct Ctx {
     int64_t opt_batch = 0;           // CG iterations launched ahead of the host's done-flag poll; 0 = by problem size (auto_batch)
     int64_t opt_chol_blocked = 1;    // mA > 64: blocked potrf/trsm/syrk chain (0: one-workgroup right-looking kernel)
     // Cauchy search, per breakpoint: 0 = downdate the Gram matrix A_free A_free' and refactor it (O(mA^3), the default: its
-    // factor is as accurate as the reference's from-scratch rebuild), 1 = rank-one downdate of the factor itself (O(mA^2),
-    // half the time at mA = 64; errors accumulate over the breakpoints — measured on the 48-parameter NLS: after 29 downdates
-    // a search direction P(-g) with ||g||/||P(-g)|| = 1.7e7 came out different enough to take one more breakpoint than
-    // the oracle, where the refactoring path agrees with it to 1e-9)
+    // factor is as accurate as the reference's from-scratch rebuild), 1 = for mA > 64: rank-one downdate of the factor itself
+    // (O(mA^2)), refreshed from scratch every kDowndateRefresh breakpoints.  Errors accumulate over the downdates — measured on the
+    // 48-parameter NLS (mA = 2, when the one-wave kernel for mA <= 64 still existed): after 29 of them a search direction P(-g)
+    // with ||g||/||P(-g)|| = 1.7e7 took one more breakpoint than the oracle; after 40, with A_free A_free' close to singular, the
+    // projections had left null(A).  Up to 64 rows the refactoring path costs the same, so it is the only one there.
     int64_t opt_chol_downdate = 0;
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
@@ -2065,6 +2066,7 @@ static int launch_batch_size(const bh_hess* H) {
 // The first batch is sized by the previous call on the handle (consecutive subproblems of a minor loop behave alike):
 // an exact prediction means no gated launches and no host round trip inside the loop at all.
 constexpr int kFirstBatchCap = 32;
+constexpr int kDowndateRefresh = 8;     // bh_cauchy_step, chol_downdate = 1: breakpoints between two from-scratch factorisations
 
 // Launches the whole projected_cg on device vectors and returns once the host has seen the loop finish (the stream may
 // still hold over-launched no-op kernels).  gp/wlp/wup: n doubles readable in 16-byte chunks; wp: output.
@@ -2830,16 +2832,20 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
         if (index > 0 && mA > 0) {
-            if (g_ctx.opt_chol_downdate) {
+            // chol_downdate = 1 only has a case where refactoring is expensive (mA > 64: blocked factorisation, 0.21 ms at mA = 256);
+            // up to 64 rows the register-panel Cholesky (18.5 us) costs what the rank-one downdate costs (20 us), so the factor is
+            // always rebuilt from the downdated Gram matrix there — as accurate as the reference's from-scratch rebuild.
+            const bool factor_downdate = g_ctx.opt_chol_downdate && mA > 64;
+            if (factor_downdate && (index % kDowndateRefresh) == 0) {
+                // every kDowndateRefresh-th breakpoint the factor is rebuilt from the device-side mask: hyperbolic downdates lose
+                // accuracy cumulatively, and without bound once A_free A_free' approaches singularity (c = sqrt(1 - s^2) -> 0)
+                BH_TRY(launch_reduced_factor(P, true, (const CgState*)c.d_state));
+            } else if (factor_downdate) {
                 P->M_valid = false;     // only the factor follows the active set on this path
                 // add_active!: one more fixed variable = rank-one downdate of chol(A_free A_free'), O(mA^2)
                 P->linv_valid = false;
-                if (mA <= 64)
-                    hipLaunchKernelGGL(chol_downdate_small_kernel, dim3(1), dim3(64), 0, s, P->Lr, (const double*)P->Ad, P->ldA, mA, P->info,
-                                       (const CgState*)c.d_state);
-                else
-                    hipLaunchKernelGGL(chol_downdate_kernel, dim3(1), dim3(CG_T), (size_t)mA * sizeof(double), s, P->Lr, (const double*)P->Ad,
-                                       P->ldA, mA, P->info, (const CgState*)c.d_state);
+                hipLaunchKernelGGL(chol_downdate_kernel, dim3(1), dim3(CG_T), (size_t)mA * sizeof(double), s, P->Lr, (const double*)P->Ad,
+                                   P->ldA, mA, P->info, (const CgState*)c.d_state);
             } else {
                 // refactor from the downdated Gram matrix, O(mA^3)
                 hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,

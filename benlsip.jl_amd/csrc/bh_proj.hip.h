@@ -510,51 +510,13 @@ __global__ __launch_bounds__(256) void chol_syrk_kernel(double* __restrict__ M, 
 }
 
 // Rank-one Cholesky DOWNDATE: L L' <- L L' - a a' with a = column `ind` (state->status) of A — what add_active! does to
-// A_free A_free' when one more variable becomes fixed.  O(m^2) instead of refactoring (O(m^3)); hyperbolic rotations in
-// the reciprocal-diagonal form: s = a_k / l_kk, c = sqrt(1 - s^2), l_kk <- c l_kk, l_ik <- (l_ik - s a_i)/c,
-// a_i <- c a_i - s l_ik.  m <= 64: one wave, row i of L in lane i's registers, 64 unrolled steps of two v_readlane
-// broadcasts + one rsqrt.  A non-positive 1 - s^2 (the downdated matrix is no longer positive definite) raises info.
-__global__ __launch_bounds__(64) void chol_downdate_small_kernel(double* __restrict__ L, const double* __restrict__ A, int64_t ldA, int m,
-                                                                 int* info, const CgState* st) {
-    if (st->done) return;
-    const int ind = st->status;
-    if (ind < 0) return;
-    const int lane = threadIdx.x;
-    double row[64];
-#pragma unroll
-    for (int k = 0; k < 64; ++k) row[k] = (lane < m && k <= lane && k < m) ? L[lane + (int64_t)k * m] : 0.0;
-    double dinv = (lane < m) ? L[(int64_t)m * m + lane] : 0.0;
-    double a = (lane < m) ? A[(int64_t)lane * ldA + ind] : 0.0;
-    int bad = 0;
-#pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        if (k < m) {
-            const double ak = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), k), __builtin_amdgcn_readlane(__double2loint(a), k));
-            const double dk = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(dinv), k),
-                                               __builtin_amdgcn_readlane(__double2loint(dinv), k));
-            const double sn = ak * dk;
-            const double t = fma(-sn, sn, 1.0);
-            if (!(t > 0.0) && bad == 0) bad = k + 1;
-            double rc = __builtin_amdgcn_rsq(t);  // 1/c: hardware seed + two Newton steps (t is a normal number in (0, 1])
-            rc = rc * fma(-0.5 * t * rc, rc, 1.5);
-            rc = rc * fma(-0.5 * t * rc, rc, 1.5);
-            const double c = t * rc;
-            if (lane == k) { row[k] = row[k] * c; dinv = dinv * rc; }
-            else if (lane > k) {
-                const double lik = (row[k] - sn * a) * rc;
-                a = fma(c, a, -sn * lik);
-                row[k] = lik;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 64; ++k)
-        if (lane < m && k <= lane && k < m) L[lane + (int64_t)k * m] = row[k];
-    if (lane < m) L[(int64_t)m * m + lane] = dinv;
-    if (lane == 0 && bad != 0) info[0] = bad;
-}
-
-// The same for any m: one workgroup, L in global memory (column k is contiguous), a in LDS.
+// A_free A_free' when one more variable becomes fixed.  O(m^2) instead of refactoring (O(m^3)); hyperbolic rotations:
+// s = a_k / l_kk, c = sqrt(1 - s^2), l_kk <- c l_kk, l_ik <- (l_ik - s a_i)/c, a_i <- c a_i - s l_ik.  A non-positive 1 - s^2
+// (the downdated matrix is no longer positive definite) raises info.  Used for m > 64 only (option chol_downdate = 1): up to
+// 64 rows refactoring the downdated Gram matrix costs the same and does not accumulate error (round 3: on the pinned operands of
+// tests/golden/cauchy_events.json, mA = 2 and A_free A_free' close to singular, 40 downdates in a row left a factor whose
+// projections were no longer in null(A); the one-wave register kernel for m <= 64 went with that finding).
+// One workgroup, L in global memory (column k is contiguous), a in LDS.
 __global__ __launch_bounds__(CG_T) void chol_downdate_kernel(double* __restrict__ L, const double* __restrict__ A, int64_t ldA, int m,
                                                              int* info, const CgState* st) {
     if (st->done) return;

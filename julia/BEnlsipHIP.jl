@@ -8,7 +8,8 @@
 #
 # What it shadows (all Float64 methods next to the package's parametric ones):
 #   hot path          Base.:*(H, v), vthv, projection!, projected_cg                         (src/basic_tralcnlss.jl:92-106, :690-764; poly:158-170)
-#   callers           minor_iterate, cauchy_step; opt-in: inner_step with device-resident vectors (:394-460, :574-675)
+#   callers           minor_iterate (:649-675); opt-in: cauchy_step (device_cauchy_step!), inner_step with device-resident
+#                     vectors (resident_inner_step!) (:394-460, :574-639)
 #   row-shard seams   new_point, evaluate_al, first_derivatives (+ second_derivatives), least_squares_multipliers
 #                     (:32-85, :887-903): mx and g all-reduced so that a multi-rank run stays in lock-step
 #   opt-in            update_chol! (skip the host factor), reference_projection_form!
@@ -150,9 +151,24 @@ end
 # cauchy_step(x, g, H, chol_aat, lincons, delta) — src/basic_tralcnlss.jl:574-639 — device-resident breakpoint search.  The
 # library leaves its own active set at the final one; lincons is brought to the state the reference's method leaves
 # behind (fixvars + one refreshed factor instead of one O(p^3) rebuild per breakpoint).
+# OPT-IN since round 3 (BEnlsipHIP.device_cauchy_step!(true)): the default configuration shadows exactly the rows of SURVEY.md
+# §8(a) — H*v, vthv, projection!, projected_cg, minor_iterate — and leaves the reference's own cauchy_step in charge, whose H*d
+# and projection! calls still reach the device one by one.  Reason: near a critical point the search direction P(-g) cancels
+# 1e7 .. 1e9 of its digits and the breakpoint sequence is decided by rounding — in the reference's own arithmetic too
+# (tests/test_oracle_cpu.py::test_cauchy_search_is_multimodal_on_the_pinned_operands) — so a second implementation of the
+# search legitimately lands on another active set there; a drop-in should not add that source of divergence unasked.
+const DEVICE_CAUCHY_STEP = Ref(false)
+device_cauchy_step!(flag::Bool = true) = (DEVICE_CAUCHY_STEP[] = flag)
+
 function BEnlsip.cauchy_step(x::Vector{Float64}, g::Vector{Float64}, H::BEnlsip.AlHessian{Float64},
                              chol_aat::Cholesky{Float64,Matrix{Float64}}, lincons::BEnlsip.MixedConstraints{Float64},
                              delta::Float64)
+    if !DEVICE_CAUCHY_STEP[]
+        # the reference's own method (more general signature); its H*d / projection! calls are routed to the device above
+        return invoke(BEnlsip.cauchy_step, Tuple{Vector{T},Vector{T},BEnlsip.AlHessian{T},Cholesky{T,Matrix{T}},
+                                                 BEnlsip.MixedConstraints{T},T} where T,
+                      x, g, H, chol_aat, lincons, delta)
+    end
     n = length(x)
     s_c = Vector{Float64}(undef, n)
     chunks = zeros(UInt64, length(lincons.fixvars.chunks))

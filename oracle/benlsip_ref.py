@@ -227,15 +227,22 @@ def add_active(lincons: MixedConstraints, chol_aat_L: np.ndarray, ind) -> None:
 # --------------------------------------------------------------------------- #
 # factor_to_boundary — src/basic_tralcnlss.jl:793-809
 # --------------------------------------------------------------------------- #
+def _julia_min(a: float, b: float) -> float:
+    """Julia's ``min`` propagates NaN (``min(Inf, NaN) === NaN``); Python's built-in drops it when it comes second."""
+    if a != a or b != b:
+        return math.nan
+    return min(a, b)
+
+
 def factor_to_boundary(p, w, w_l, w_u, atol: float = 1e-10) -> float:
     gamma = math.inf
     with np.errstate(divide="ignore", invalid="ignore"):
         neg = p <= -atol
         pos = p >= atol
         if neg.any():
-            gamma = min(gamma, float(np.min((w_l[neg] - w[neg]) / p[neg])))
+            gamma = _julia_min(gamma, float(np.min((w_l[neg] - w[neg]) / p[neg])))     # np.min propagates NaN like Julia's min
         if pos.any():
-            gamma = min(gamma, float(np.min((w_u[pos] - w[pos]) / p[pos])))
+            gamma = _julia_min(gamma, float(np.min((w_u[pos] - w[pos]) / p[pos])))
     return gamma
 
 

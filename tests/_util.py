@@ -75,3 +75,126 @@ def assert_rounding_dominated(diff):
     for name, va, vb, extra in why:
         assert name.startswith("rho vs"), "driver decision %r differs (oracle %r, device %r) at log entry %d" % (name, va, vb, k)
         assert extra["ared_in_ulps_of_mx"] <= 512.0, (k, name, extra)
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# Pinned operands of Cauchy searches whose outcome is decided by rounding (tests/golden/cauchy_events.json, written by
+# tests/golden/make_cauchy_events.py from a device shadow solve of the 48-parameter NLS instance)
+# --------------------------------------------------------------------------------------------------------------------------
+def load_cauchy_events():
+    import json
+    import os
+    from nls_problem import NLSProblem
+    data = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cauchy_events.json")))
+    P = NLSProblem(256, 48, 2, seed=1)
+    hx = lambda seq: np.array([float.fromhex(v) for v in seq])
+    events = []
+    for e in data["events"]:
+        x = hx(e["x"])
+        fix0 = np.zeros(P.n, dtype=bool)
+        fix0[e["fix0"]] = True
+        events.append(dict(minor=e["minor"], x=x, g=hx(e["g"]), delta=float.fromhex(e["delta"]), mu=float.fromhex(e["mu"]), fix0=fix0,
+                           J=P.jac_r(x), C=P.jac_c(x), s_dev=hx(e["s_dev"]), s_cpu=hx(e["s_cpu"]), fix_dev=e["fix_dev"], fix_cpu=e["fix_cpu"]))
+    return P, events
+
+
+class ReducedFormOps(R.NumpyOps):
+    """A second CPU restatement of the SAME projector (the form the device uses): zero the fixed components,
+    project the free part onto null(A_free) with chol(A_free A_free').  Mathematically identical to the reference's augmented
+    form; the rounding differs."""
+
+    def projection(self, lincons, r):
+        from scipy.linalg import solve_triangular
+        free = ~lincons.fixvars
+        Af, rf = lincons.lineq[:, free], r[free]
+        v = np.zeros_like(r)
+        if Af.shape[0] == 0:
+            v[free] = rf
+            return v
+        L = np.linalg.cholesky(Af @ Af.T)
+        y = solve_triangular(L.T, solve_triangular(L, Af @ rf, lower=True), lower=False)
+        v[free] = rf - Af.T @ y
+        return v
+
+
+def cauchy_outcomes(P, e, ops, samples, seed):
+    """The oracle's cauchy_step (src/basic_tralcnlss.jl:574-639) on the event's operands: nominal g first, then `samples - 1`
+    copies of g perturbed by at most one unit in the last place per entry.  Returns [(s, final active set as a tuple)]."""
+    L0 = R.chol_lower(P.A @ P.A.T)
+    H = R.AlHessian(e["J"], e["C"], e["mu"])
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(samples):
+        g = e["g"] if k == 0 else e["g"] * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, e["g"].shape[0]))
+        lc = R.make_mixed_constraints(P.A, L0, e["fix0"].copy(), l=P.x_l, u=P.x_u)
+        s = R.cauchy_step(e["x"], g, H, L0, lc, e["delta"], ops)
+        out.append((s, tuple(np.flatnonzero(lc.fixvars))))
+    return out
+
+
+def model_value(e, s):
+    """phi(s) = g.s + 1/2 s'Hs — what the Cauchy search minimises along the projected-gradient path (:610-611)."""
+    return float(e["g"] @ s + 0.5 * R.vthv(R.AlHessian(e["J"], e["C"], e["mu"]), s))
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# Re-association variants of the oracle's H*v (the band the reference's own arithmetic spans on config 1)
+# --------------------------------------------------------------------------------------------------------------------------
+def _hmul_mu_outside(H, v):
+    return H.J.T @ (H.J @ v) + H.mu * (H.C.T @ (H.C @ v))
+
+
+def _hmul_sequential(H, v):
+    def mv(M, x):          # plain left-to-right dot products, row by row
+        out = np.zeros(M.shape[0])
+        for i in range(M.shape[0]):
+            acc = 0.0
+            for j in range(M.shape[1]):
+                acc += M[i, j] * x[j]
+            out[i] = acc
+        return out
+    return mv(H.J.T, mv(H.J, v)) + mv(H.C.T, mv(H.mu * H.C, v))
+
+
+def _hmul_reversed(H, v):
+    Jr, Cr = H.J[::-1], H.C[::-1]
+    return (Jr.T @ (Jr @ v)) + (Cr.T @ ((H.mu * Cr) @ v))
+
+
+HMUL_VARIANTS = {"reference order (mu*C)*v": None, "mu*(C'(C v))": _hmul_mu_outside, "long double": hmul_longdouble,
+                 "sequential sums": _hmul_sequential, "rows reversed": _hmul_reversed}
+
+
+class OracleVariantOps(R.NumpyOps):
+    """The oracle with its H*v evaluated in another, mathematically equivalent order."""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def hmul(self, H, v):
+        return R.hmul(H, v) if self.fn is None else self.fn(H, v)
+
+    def projected_cg(self, g_minor, H, w_l, w_u, lincons, kappa2):
+        w, status, _ = R.projected_cg(g_minor, H, w_l, w_u, lincons, kappa2, **({} if self.fn is None else {"hmul_fn": self.fn}))
+        return w, status
+
+
+def sphere_opt_measure(xs, ys):
+    """test/problems/sphere_regression.jl:58-61: || x - P(x - grad L) || with P the projection onto {Ax = b, l <= x <= u}."""
+    import sphere_problem as sp
+    grad = sp.jac_r(xs).T @ sp.r(xs) + sp.jac_c(xs).T @ ys
+    return float(np.linalg.norm(xs - R.projection_polyhedron_small(xs - grad, sp.A, sp.b, sp.x_l, sp.x_u)))
+
+
+_SPHERE_BAND = {}
+
+
+def sphere_oracle_band():
+    """opt_measure of the ORACLE's config-1 solve under each re-association variant of its own H*v: {variant: value}."""
+    import sphere_problem as sp
+    if not _SPHERE_BAND:
+        for name, fn in HMUL_VARIANTS.items():
+            xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, max_outer_iter=100, max_inner_iter=250,
+                                  ops=OracleVariantOps(fn))
+            _SPHERE_BAND[name] = sphere_opt_measure(xs, ys)
+    return dict(_SPHERE_BAND)

@@ -134,7 +134,7 @@ class ShadowOps:
     the same operands, so the first discrepancy in status / iteration count / active set is pinned to one call, together
     with the device's tie log for it (such a discrepancy must be a logged tie)."""
 
-    def __init__(self, dev_ops, relnorm_tol=1e-6):
+    def __init__(self, dev_ops, relnorm_tol=1e-6, sens_samples=None):
         self.dev = dev_ops
         self.cpu = R.NumpyOps()
         self.events = []          # discrepancies: dicts
@@ -143,6 +143,15 @@ class ShadowOps:
         self.worst = {}           # op -> largest relative deviation seen
         self.min_margin = (np.inf, None)
         self.tol = relnorm_tol
+        self.n_cg_samples = sens_samples or 3          # perturbed oracle evaluations behind "oracle_sensitivity"
+        self.n_cauchy_samples = sens_samples or 16
+        # the driver asks the backend for whole-step methods with hasattr(): offer exactly what the device backend offers
+        if hasattr(dev_ops, "minor_iterate"):
+            self.minor_iterate = self._minor_iterate
+        if hasattr(dev_ops, "cauchy_step"):
+            self.cauchy_step = self._cauchy_step
+        if hasattr(dev_ops, "hmul_add"):
+            self.hmul_add = self._hmul_add
 
     def _rel(self, op, a, b):
         a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
@@ -161,7 +170,7 @@ class ShadowOps:
         self._rel("hmul", out, self.cpu.hmul(H[1], v))
         return out
 
-    def hmul_add(self, H, s, g):
+    def _hmul_add(self, H, s, g):
         out = self.dev.hmul_add(H[0], s, g)
         self._rel("hmul_add", out, self.cpu.hmul(H[1], s) + g)
         return out
@@ -183,7 +192,27 @@ class ShadowOps:
                                     shrink=float(np.linalg.norm(ref) / max(np.linalg.norm(r), 1e-300))))
         return out
 
-    def minor_iterate(self, x, s, g_model, H, lincons, delta, kappa2):
+    def projected_cg(self, g_minor, H, w_l, w_u, lincons, kappa2):
+        """(backends without a whole-step minor_iterate: the oracle's minor_iterate calls this, then linesearch -> vthv)"""
+        self.minor += 1
+        w, st = self.dev.projected_cg(g_minor, H[0], w_l, w_u, lincons, kappa2)
+        it_dev, ties = self.dev.last_iters, getattr(self.dev, "last_ties", None)
+        w_o, st_o, it_o = R.projected_cg(g_minor, H[1], w_l, w_u, lincons, kappa2)
+        d = self._rel("projected_cg", w, w_o)
+        if ties is not None and ties["min_margin"] < self.min_margin[0]:
+            self.min_margin = (ties["min_margin"], dict(ties, minor=self.minor))
+        if int(st) != int(st_o) or it_dev != it_o or d > self.tol:
+            rng = np.random.default_rng(self.minor)
+            sens = 0.0
+            for _ in range(self.n_cg_samples):
+                g2 = g_minor * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, g_minor.shape[0]))
+                w2, _, _ = R.projected_cg(g2, H[1], w_l, w_u, lincons, kappa2)
+                sens = max(sens, float(np.linalg.norm(w2 - w_o) / max(np.linalg.norm(w_o), 1e-300)))
+            self.events.append(dict(op="projected_cg", minor=self.minor, status_dev=int(st), status_cpu=int(st_o), iters_dev=it_dev,
+                                    iters_cpu=it_o, rel=d, oracle_sensitivity=sens, ties=ties))
+        return w, st
+
+    def _minor_iterate(self, x, s, g_model, H, lincons, delta, kappa2):
         self.minor += 1
         w, st = self.dev.minor_iterate(x, s, g_model, H[0], lincons, delta, kappa2)
         it_dev, ties = self.dev.last_iters, getattr(self.dev, "last_ties", None)
@@ -199,7 +228,7 @@ class ShadowOps:
         if int(st) != int(st_o) or it_dev != it_o or d > self.tol:
             rng = np.random.default_rng(self.minor)
             sens = 0.0
-            for _ in range(3):           # the oracle's own w under last-bit perturbations of its right-hand side
+            for _ in range(self.n_cg_samples):           # the oracle's own w under last-bit perturbations of its right-hand side
                 g2 = g_model * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, g_model.shape[0]))
                 w2, st2, _ = R.projected_cg(g2, H[1], w_l, w_u, lincons, kappa2)
                 if st2 != R.CGStatus.negative_curvature:
@@ -210,7 +239,7 @@ class ShadowOps:
                                     iters_cpu=it_o, rel=d, oracle_sensitivity=sens, ties=ties))
         return w, st
 
-    def cauchy_step(self, x, g, H, chol_aat_L, lincons, delta):
+    def _cauchy_step(self, x, g, H, chol_aat_L, lincons, delta):
         import copy
         shadow = copy.copy(lincons)
         shadow._dev = None
@@ -225,7 +254,7 @@ class ShadowOps:
             # relative accuracy is eps*||g||/||P(-g)||, whoever computes it)
             rng = np.random.default_rng(self.minor)
             sens = 0.0
-            for _ in range(16):         # (the outcome can be bimodal — e.g. 37 or 41 breakpoints — so a handful of samples is not enough)
+            for _ in range(self.n_cauchy_samples):         # (the outcome can be bimodal — e.g. 37 or 41 breakpoints — so a handful of samples is not enough)
                 sh2 = copy.copy(lincons)
                 sh2._dev = None
                 sh2.fixvars = fix0.copy()

@@ -553,49 +553,89 @@ def test_sphere_regression_through_c_abi(bh, capsys, ops_cls):
               % (ops_cls.__name__, opt_measure, np.linalg.norm(sp.c(xs)), sum(e[0] == "minor" for e in log)))
     assert np.linalg.norm(sp.c(xs)) < R.SQRT_EPS
     assert R.is_feasible(xs, sp.A, sp.x_l, sp.x_u, sp.b)
-    # The reference's third inequality (opt_measure < 1e-7, :65) is a rounding-fragile number: the ORACLE itself gives 7.2e-8,
-    # 3.2e-7, 3.6e-7 and 4.3e-8 when its H*v is evaluated as (mu*C)*v [reference order], mu*(C'(Cv)), in long double, or with
-    # sequential sums, because the last trust-region iterates take their accept / resize decisions on rho = ared/pred with
-    # |ared| worth 3-4 ulps of mx (printed below: first differing decision).  Through the projected_cg and minor_iterate ABIs the
-    # device run stays on the oracle's side of those iterates and meets the reference's bound (6.80e-8, asserted as the reference
-    # asserts it); with the Cauchy search on the device as well it leaves the trajectory at such an iterate and ends in the upper
-    # part of that band (3.15e-7): asserted at the band's edge, together with the reason.
-    from _util import first_decision_difference
-    from _util import assert_rounding_dominated
+    # The reference's third inequality (opt_measure < 1e-7, :65) is decided by rounding: the ORACLE itself meets it in the
+    # reference's evaluation order of H*v and misses it under mathematically equivalent ones (tests/test_oracle_cpu.py::
+    # test_reference_bound_on_config_1_is_decided_by_rounding_in_the_oracle_itself), because the last trust-region iterates
+    # accept / resize on rho = ared/pred with |ared| worth 3-4 ulps of mx (printed below: first differing decision).  Which
+    # side a device variant ends on has flipped with unrelated kernel edits (round 2: 6.8e-8 / 3.15e-7; round 3: 4.2e-8 ...
+    # 7.8e-8 on all four).  ONE rule for every variant, with the band computed here: within a factor 2 of the largest value the
+    # oracle's own re-associations produce; whether the reference's 1e-7 is met is printed, not fitted.
+    from _util import assert_rounding_dominated, first_decision_difference, sphere_oracle_band
     log_ref = []
     R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, max_outer_iter=100, max_inner_iter=250, log=log_ref)
     diff = first_decision_difference(log_ref, log)
-    if diff is not None:
-        with capsys.disabled():
+    band = sphere_oracle_band()
+    with capsys.disabled():
+        if diff is not None:
             print("    first driver decision that differs from the oracle's: log entry %d of %d: %s" % (diff[0], len(log_ref), diff[3]))
+        print("    opt_measure %.3e: %s the reference's 1e-7; oracle band under re-association %.2e .. %.2e; bound 2 x %.2e, used %.0f %%"
+              % (opt_measure, "meets" if opt_measure < 1e-7 else "MISSES", min(band.values()), max(band.values()), max(band.values()),
+                 100.0 * opt_measure / (2.0 * max(band.values()))))
+    if diff is not None:
         assert_rounding_dominated(diff)
-    if ops_cls in (HipOpsDeviceAll, HipOpsResident):
-        assert opt_measure < 4e-7          # measured 3.15e-7: leaves the oracle's trajectory at the noise rho of log entry 75
-    else:
-        assert opt_measure < 1e-7          # measured 6.80e-8 (oracle 7.16e-8): the reference's own bound
+    assert opt_measure < 2.0 * max(band.values())
 
 
-def test_sphere_regression_with_the_fused_general_iteration(bh, capsys):
-    """The same solve with the four-kernel iteration for linear equalities (cg_fused = 2, opt-in): it forms pHp as
-    ||Jp||^2 + mu ||Cp||^2 instead of dot(p, H*p) — the same number in different last bits — so the run leaves the oracle's
-    trajectory at an earlier noise rho and ends in the upper part of the band the oracle itself spans (measured 3.15e-7)."""
-    from _util import first_decision_difference
-    from _util import assert_rounding_dominated
-    bh.set_option("cg_fused", 2)
+@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("ops_cls", [HipOps, HipOpsDeviceMinor, HipOpsDeviceAll], ids=["pcg_abi", "minor_iterate_abi", "cauchy_abi"])
+def test_sphere_regression_shadow_solve_every_variant(bh, capsys, ops_cls, fused):
+    """config 1 (n = 3, d = 4, q = 1, mA = 1) as a SHADOW solve — device and oracle evaluated on identical operands
+    at every hot-path call — for every ops variant x every CG iteration shape.  On n = 3 there is no room for a bug to hide:
+      * H*v, H*s+g, vthv agree to 1e-12 of their result, projections to 1e-12 of their operand;
+      * every projected_cg / minor iterate has the oracle's exit status and iteration count, every Cauchy search the oracle's
+        final active set — no exception;
+      * w and the Cauchy step are cancelling computations near the solution (measured here: the ORACLE's own w moves by up to
+        2e-6, its Cauchy step by up to 6e-2, when g is perturbed by one unit in the last place — at n = 3): they must lie within
+        8 x the spread of 16 such perturbed oracle evaluations (or 1e-12), the used fraction is printed."""
+    bh.set_option("cg_fused", fused)
+    try:
+        sh = ShadowOps(ops_cls(bh), relnorm_tol=1e-12, sens_samples=16)
+        xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, max_outer_iter=100, max_inner_iter=250, ops=sh)
+    finally:
+        bh.set_option("cg_fused", 1)
+    from _util import sphere_opt_measure
+    worst_ratio, worst_ev = 0.0, None
+    for e in sh.events:
+        assert e["op"] != "projection", e
+        if e["op"] in ("projected_cg", "minor_iterate"):
+            assert (e["status_dev"], e["iters_dev"]) == (e["status_cpu"], e["iters_cpu"]), e
+        if e["op"] == "cauchy_step":
+            assert e["fix_dev"] == e["fix_cpu"], {k: v for k, v in e.items() if k != "operands"}
+        ratio = e["rel"] / max(8.0 * e["oracle_sensitivity"], 1e-12)
+        if ratio > worst_ratio:
+            worst_ratio, worst_ev = ratio, {k: v for k, v in e.items() if k not in ("operands", "ties")}
+    with capsys.disabled():
+        print("[sphere shadow, %s, cg_fused=%d] %d minor iterates, opt_measure %.2e; worst deviation per operator %s; %d calls above 1e-12, "
+              "worst uses %.0f %% of 8 x the oracle's own spread: %s"
+              % (ops_cls.__name__, fused, sh.minor, sphere_opt_measure(xs, ys), {k: float("%.1e" % v) for k, v in sh.worst.items()},
+                 len(sh.events), 100.0 * worst_ratio, worst_ev))
+    for op in ("hmul", "hmul_add", "vthv", "projection"):
+        assert sh.worst.get(op, 0.0) <= 1e-12, (op, sh.worst[op])
+    assert worst_ratio <= 1.0, worst_ev
+
+
+@pytest.mark.parametrize("fused", [0, 2])
+def test_sphere_regression_with_the_other_iteration_shapes(bh, capsys, fused):
+    """The same solve with the seven-kernel (cg_fused = 0: pHp = dot(p, H*p) exactly as the reference forms it) and the four-kernel
+    (cg_fused = 2) iteration for linear equalities; the default three-kernel shape runs in the test above.  The shapes round pHp
+    differently, so each leaves the oracle's trajectory at its own noise rho; the same rule as above applies to all of them."""
+    from _util import assert_rounding_dominated, first_decision_difference, sphere_opt_measure, sphere_oracle_band
+    bh.set_option("cg_fused", fused)
     try:
         ops, log, log_ref = HipOps(bh), [], []
         kw = dict(max_outer_iter=100, max_inner_iter=250)
         xs, ys = R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, ops=ops, log=log, **kw)
         R.tralcnllss(sp.x0, sp.r, sp.jac_r, sp.c, sp.jac_c, sp.A, sp.b, sp.x_l, sp.x_u, log=log_ref, **kw)
-        grad = sp.jac_r(xs).T @ sp.r(xs) + sp.jac_c(xs).T @ ys
-        opt_measure = float(np.linalg.norm(xs - R.projection_polyhedron_small(xs - grad, sp.A, sp.b, sp.x_l, sp.x_u)))
+        opt_measure, band = sphere_opt_measure(xs, ys), sphere_oracle_band()
         diff = first_decision_difference(log_ref, log)
         with capsys.disabled():
-            print("[sphere regression, HipOps, cg_fused=2] opt_measure = %.3e; first differing decision: %s" % (opt_measure, None if diff is None else (diff[0], diff[3])))
+            print("[sphere regression, HipOps, cg_fused=%d] opt_measure = %.3e (%s the reference's 1e-7; %.0f %% of 2 x the oracle band's %.2e); "
+                  "first differing decision: %s" % (fused, opt_measure, "meets" if opt_measure < 1e-7 else "MISSES",
+                                                    100.0 * opt_measure / (2.0 * max(band.values())), max(band.values()), None if diff is None else (diff[0], diff[3])))
         assert np.linalg.norm(sp.c(xs)) < R.SQRT_EPS and R.is_feasible(xs, sp.A, sp.x_l, sp.x_u, sp.b)
         if diff is not None:
             assert_rounding_dominated(diff)
-        assert opt_measure < 4e-7
+        assert opt_measure < 2.0 * max(band.values())
     finally:
         bh.set_option("cg_fused", 1)
 
@@ -795,7 +835,8 @@ def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
 # ----------------------------------------------------------------------------- Cauchy step on the device (f-3)
 @pytest.fixture(params=[1, 0], ids=["factor_downdate", "gram_downdate_refactor"])
 def chol_downdate(request, bh):
-    """Per breakpoint: rank-one downdate of chol(A_free A_free') (default) or downdate of the Gram matrix + refactorisation."""
+    """Per breakpoint: downdate of the Gram matrix + refactorisation (0, the default), or — for mA > 64 — rank-one downdates of
+    chol(A_free A_free') with a from-scratch rebuild every 8th breakpoint (1)."""
     bh._lib.lib().bh_set_option(b"chol_downdate", request.param)
     yield request.param
     bh._lib.lib().bh_set_option(b"chol_downdate", 0)
@@ -840,6 +881,52 @@ def test_cauchy_step_parity(bh, chol_downdate, d, n, mA, nact, delta_scale, seed
     # the handle now holds the final active set: a projection agrees with the oracle's
     r = rng.standard_normal(n)
     assert np.linalg.norm(bh.projection(cons, r) - R.projection(cons_o, r)) <= 1e-10 * np.linalg.norm(r)
+
+
+def test_cauchy_step_on_the_pinned_multimodal_operands(bh, capsys, chol_downdate):
+    """the worst Cauchy discrepancies of the device shadow solve, with their operands committed
+    (tests/golden/cauchy_events.json).  tests/test_oracle_cpu.py shows that on these operands the ORACLE ALONE lands on several
+    final active sets under 1-ulp perturbations of g, and a reduced-form CPU restatement on yet others — the outcome is not
+    determined in fp64 (trust region 1e-11 .. 1e-14, ||g||/||P(-g)|| = 1e7 .. 1e8).  What CAN be demanded of the device there,
+    and can fail:
+      * the step is feasible: inside the trust region and the bounds, in null(A) as closely as the CPU restatements' own steps;
+      * its model value phi(s) = g.s + s'Hs/2 — what the search minimises — lies inside the range the CPU outcomes span (5 %
+        margin), and so does the size of its final active set (+-2);
+      * where CPU outcomes have exactly the device's final active set, the device's step is as close to them as they are to each
+        other (or 1e-6); where every CPU outcome has the SAME active set (the two unimodal events), so has the device.
+    (Both per-breakpoint factor updates; since round 3 chol_downdate = 1 applies to mA > 64 only — this test found its one-wave
+    kernel for mA <= 64 walking to the corner of the trust region on event 511: 46 active bounds, |As|/|A||s| = 4e-6.)"""
+    from _util import ReducedFormOps, cauchy_outcomes, load_cauchy_events, model_value
+    P, events = load_cauchy_events()
+    for e in events:
+        H = bh.AlHessian(e["J"], e["C"], e["mu"])
+        cons = bh.MixedConstraints(P.A, None, None, l=P.x_l, u=P.x_u)
+        s, info = bh.cauchy_step(e["x"], e["g"], H, cons, e["delta"], full_output=True)
+        key_dev = tuple(np.flatnonzero(cons.fixvars))
+        cpu = cauchy_outcomes(P, e, R.NumpyOps(), 32, seed=e["minor"]) + cauchy_outcomes(P, e, ReducedFormOps(), 32, seed=e["minor"])
+        phis = np.array([model_value(e, sc) for sc, _ in cpu])
+        sizes = [len(k) for _, k in cpu]
+        as_rel = lambda v: float(np.linalg.norm(P.A @ v) / (np.linalg.norm(P.A) * max(np.linalg.norm(v), 1e-300)))
+        phi_dev = model_value(e, s)
+        same_set = [sc for sc, k in cpu if k == key_dev]
+        nearest = min(relnorm(s, sc) for sc, _ in cpu)
+        with capsys.disabled():
+            print("[pinned Cauchy event, minor iterate %d, chol_downdate=%d] device: %d active bounds, phi %.4e, |As|/|A||s| %.1e; CPU outcomes: sizes %d..%d "
+                  "(%d distinct sets), phi %.4e .. %.4e, |As|/|A||s| <= %.1e; same set on the CPU: %s; nearest CPU outcome at %.1e"
+                  % (e["minor"], chol_downdate, len(key_dev), phi_dev, as_rel(s), min(sizes), max(sizes), len({k for _, k in cpu}), phis.min(), phis.max(),
+                     max(as_rel(sc) for sc, _ in cpu), "no" if not same_set else "yes, steps %.1e apart" % min(relnorm(s, sc) for sc in same_set), nearest))
+        assert np.max(np.abs(s)) <= e["delta"] * (1 + 1e-12)
+        assert np.all(e["x"] + s <= P.x_u + 1e-12) and np.all(e["x"] + s >= P.x_l - 1e-12)
+        assert as_rel(s) <= 10.0 * max(as_rel(sc) for sc, _ in cpu) + 1e-12
+        assert phis.min() - 0.05 * abs(phis.min()) <= phi_dev <= phis.max() + 0.05 * abs(phis.max()), (phi_dev, phis.min(), phis.max())
+        assert min(sizes) - 2 <= len(key_dev) <= max(sizes) + 2
+        if same_set:
+            # same breakpoint sequence: as close to the CPU outcomes with that set as they are to each other (or 1e-6)
+            spread = max(relnorm(sa, sb) for sa in same_set[:8] for sb in same_set)
+            assert min(relnorm(s, sc) for sc in same_set) <= max(1e-6, spread), (min(relnorm(s, sc) for sc in same_set), spread)
+        if len({k for _, k in cpu}) == 1:
+            assert key_dev == cpu[0][1]
+        H.close(); cons.close()
 
 
 # ----------------------------------------------------------------------------- wide J (n > 8192)
