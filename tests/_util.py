@@ -156,8 +156,17 @@ def _hmul_sequential(H, v):
     return mv(H.J.T, mv(H.J, v)) + mv(H.C.T, mv(H.mu * H.C, v))
 
 
+def _cached(H, key, make):
+    """Derived copies of J are built once per AlHessian (the variants are called hundreds of times per CG run)."""
+    cache = H.__dict__.setdefault("_variant_cache", {})
+    if key not in cache:
+        cache[key] = make()
+    return cache[key]
+
+
 def _hmul_reversed(H, v):
-    Jr, Cr = H.J[::-1], H.C[::-1]
+    Jr = _cached(H, "rev", lambda: np.asfortranarray(H.J[::-1]))
+    Cr = H.C[::-1]
     return (Jr.T @ (Jr @ v)) + (Cr.T @ ((H.mu * Cr) @ v))
 
 
@@ -198,3 +207,89 @@ def sphere_oracle_band():
                                   ops=OracleVariantOps(fn))
             _SPHERE_BAND[name] = sphere_opt_measure(xs, ys)
     return dict(_SPHERE_BAND)
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# How much of each tolerance the run actually used (printed at the end of the session by tests/conftest.py)
+# --------------------------------------------------------------------------------------------------------------------------
+TOL_USED = {}
+
+
+def note_tol(label, value, bound, detail=""):
+    """Record value / bound for the end-of-session table; returns the ratio."""
+    ratio = float(value) / float(bound) if bound > 0 else (0.0 if value == 0 else float("inf"))
+    n, worst, wdetail, vals = TOL_USED.get(label, (0, -1.0, "", (0.0, 0.0)))
+    if ratio > worst:
+        worst, wdetail, vals = ratio, detail, (float(value), float(bound))
+    TOL_USED[label] = (n + 1, worst, wdetail, vals)
+    return ratio
+
+
+def assert_w_close(w, w_ref, tol, label, detail=""):
+    """||w - w_ref|| <= tol ||w_ref||, with the used fraction of the tolerance recorded under `label`."""
+    rel = relnorm(w, w_ref)
+    note_tol(label, rel, tol, detail)
+    assert rel <= tol, (label, detail, rel, tol)
+
+
+def _hmul_c_order(H, v):
+    Jc = _cached(H, "c", lambda: np.ascontiguousarray(H.J))
+    return Jc.T @ (Jc @ v) + H.C.T @ ((H.mu * H.C) @ v)
+
+
+def _hmul_row_chunks(H, v, chunk=1024):
+    out = H.C.T @ ((H.mu * H.C) @ v)
+    for lo in range(0, H.J.shape[0], chunk):
+        Jb = H.J[lo:lo + chunk]
+        out = out + Jb.T @ (Jb @ v)
+    return out
+
+
+def _hmul_row_blocks(k):
+    """J'(J v) as the sum over k contiguous row blocks, added in block order (what k row-sharded ranks compute)."""
+    def fn(H, v):
+        out = H.C.T @ ((H.mu * H.C) @ v)
+        d = H.J.shape[0]
+        base, extra = divmod(d, k)
+        lo = 0
+        for b in range(k):
+            hi = lo + base + (1 if b < extra else 0)
+            out = out + H.J[lo:hi].T @ (H.J[lo:hi] @ v)
+            lo = hi
+        return out
+    return fn
+
+
+CG_HMUL_VARIANTS = {"reference": None, "long double": hmul_longdouble, "C-order sums": _hmul_c_order, "1024-row chunks": _hmul_row_chunks,
+                    "rows reversed": _hmul_reversed, "2 row blocks": _hmul_row_blocks(2), "3 row blocks": _hmul_row_blocks(3),
+                    "4 row blocks": _hmul_row_blocks(4), "7 row blocks": _hmul_row_blocks(7)}
+
+
+def oracle_iteration_band(g, H, w_l, w_u, cons, kappa2, variants=None, perturbed=0):
+    """Iteration counts (and exit statuses) of the ORACLE's projected_cg when its H*p is summed in mathematically equivalent
+    orders — and, with `perturbed` = k, on k copies of the instance whose J carries relative perturbations of 1e-15 (seeded):
+    {variant: (status, iters)}.  On an ill-conditioned instance finite-precision CG is chaotic — this is the band inside which an
+    iteration count means anything."""
+    out = {}
+    for name, fn in CG_HMUL_VARIANTS.items():
+        if variants is not None and name not in variants:
+            continue
+        w, st, it = R.projected_cg(g, H, w_l, w_u, cons, kappa2, **({} if fn is None else {"hmul_fn": fn}))
+        out[name] = (int(st), int(it))
+    rng = np.random.default_rng(1234)
+    for k in range(perturbed):
+        Hk = R.AlHessian(H.J * (1.0 + 1e-15 * rng.uniform(-1.0, 1.0, H.J.shape)), H.C, H.mu)
+        w, st, it = R.projected_cg(g, Hk, w_l, w_u, cons, kappa2)
+        out["J perturbed 1e-15 #%d" % k] = (int(st), int(it))
+    return out
+
+
+def assert_iters_in_oracle_band(iters, band, label, detail=""):
+    """The device's count must lie inside the oracle's own band widened on either side by the band's width (at least 5 % of the
+    count: a handful of oracle runs under-samples the spread — the device rounds every reduction of the loop differently, not only
+    H*p)."""
+    its = [it for _, it in band.values()]
+    lo, hi = min(its), max(its)
+    slack = max(hi - lo, int(np.ceil(0.05 * hi)))
+    note_tol(label, abs(iters - 0.5 * (lo + hi)), 0.5 * (hi - lo) + slack, "%s: device %d, oracle band %d..%d" % (detail, iters, lo, hi))
+    assert lo - slack <= iters <= hi + slack, (label, detail, iters, band)

@@ -52,3 +52,17 @@ def bh():
 def ref():
     import benlsip_ref
     return benlsip_ref
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """How much of each tolerance the session used (tests/_util.py::note_tol): worst value / bound per tolerance kind."""
+    try:
+        from _util import TOL_USED
+    except Exception:
+        return
+    if not TOL_USED:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "tolerance use (worst value / bound per kind)")
+    for label, (n, worst, detail, (value, bound)) in sorted(TOL_USED.items()):
+        tr.write_line("  %5.1f %%  %s  [%d checks; worst %.3e of %.3e%s]" % (100.0 * worst, label, n, value, bound, (", " + detail) if detail else ""))

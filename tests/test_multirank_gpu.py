@@ -19,7 +19,8 @@ import uuid
 import numpy as np
 import pytest
 
-from _util import R, assert_rounding_dominated, first_decision_difference, relnorm, w_tolerance
+from _util import (R, assert_iters_in_oracle_band, assert_rounding_dominated, first_decision_difference, oracle_iteration_band, relnorm,
+                   w_tolerance)
 
 pytestmark = pytest.mark.gpu
 
@@ -115,7 +116,13 @@ def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     # launch schedules, tests/multirank/tight_probe.py), and one iteration moves w by O(kappa2) — so compare the exit, the
     # count within that band, and the model value the step achieves
     w, st, it = R.projected_cg(gm, Ho, lo_b, hi_b, box, 1e-3)
-    assert int(z["box_tight_st"]) == int(st) and abs(int(z["box_tight_it"]) - it) <= 8, (int(z["box_tight_it"]), it)
+    # the oracle's own counts: its H*p re-associated (incl. 2 / 3 / 4 / 7 row blocks, what row-sharded ranks sum) and 16 copies of the
+    # instance with J perturbed by 1e-15 relative
+    band = oracle_iteration_band(gm, Ho, lo_b, hi_b, box, 1e-3, perturbed=16)
+    print("[multirank %s x%d, kappa2 = 1e-3] device %d iterations; oracle band %d..%d over %d runs"
+          % (comm, world, int(z["box_tight_it"]), min(i for _, i in band.values()), max(i for _, i in band.values()), len(band)))
+    assert int(z["box_tight_st"]) == int(st) and all(s_ == int(st) for s_, _ in band.values())
+    assert_iters_in_oracle_band(int(z["box_tight_it"]), band, "ill-conditioned CG: iteration count vs the oracle's own band", "multirank %s x%d" % (comm, world))
     model = lambda y: float(gm @ y + 0.5 * R.vthv(Ho, y))
     assert model(z["box_tight_w"]) == pytest.approx(model(w), rel=5e-3)      # measured 1.0e-3 with one iteration more
     assert int(z["box_tight_nh"]) > 24           # well past the first launch batch: the launch-ahead decisions were exercised

@@ -13,7 +13,7 @@ import pytest
 
 import benlsip_ref as R
 import sphere_problem as sp
-from _util import matvec_scale, relnorm, w_tolerance
+from _util import assert_iters_in_oracle_band, assert_w_close, matvec_scale, note_tol, oracle_iteration_band, relnorm, w_tolerance
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -176,13 +176,25 @@ def test_hs48_projection_known_answer(bh):
     y = np.random.default_rng(0).random(4)
     np.testing.assert_allclose(bh.left_mul_tr(cons, y), B.T @ y, rtol=1.5e-8)
     np.testing.assert_allclose(bh.left_mul(cons, x), B @ x, rtol=1.5e-8)
-    proj = bh.projection(cons, x)
-    Ap = A @ proj
-    assert np.all(proj[fix] <= np.finfo(float).eps) and float(Ap @ Ap) <= 4 * np.finfo(float).eps
-    assert np.max(np.abs(proj - np.array(h["projection"]))) <= 1e-14
-    v = np.empty(5)
-    bh.projection_(cons, x, v)
-    assert np.array_equal(v, proj)
+    eps = np.finfo(float).eps
+    for form in (1, 0):                 # reduced form (default) and the reference's augmented form, with the reference's own bounds
+        bh.set_option("proj_form", form)
+        try:
+            cons_f = bh.MixedConstraints(A, L_aug, fix)
+            proj = bh.projection(cons_f, x)
+        finally:
+            bh.set_option("proj_form", 1)
+        Ap = A @ proj
+        print("[HS48, proj_form=%d] projection %s; ||A proj||^2 = %.2e (reference: <= eps = %.2e), max |proj - known answer| = %.2e"
+              % (form, proj, float(Ap @ Ap), eps, np.max(np.abs(proj - np.array(h["projection"])))))
+        note_tol("HS48: ||A proj||^2 vs the reference's eps (test/structures.jl:55)", float(Ap @ Ap), eps, "proj_form=%d" % form)
+        note_tol("HS48: max |proj - [0,0,0,2,-2]| vs 1e-14", float(np.max(np.abs(proj - np.array(h["projection"])))), 1e-14, "proj_form=%d" % form)
+        assert np.all(proj[fix] <= eps) and float(Ap @ Ap) <= eps                     # test/structures.jl:55-56, as the reference asserts them
+        assert np.max(np.abs(proj - np.array(h["projection"]))) <= 1e-14              # :57 / SURVEY §8c
+        v = np.empty(5)
+        bh.projection_(cons_f, x, v)
+        assert np.array_equal(v, proj)
+        cons_f.close()
 
 
 @pytest.fixture(params=[1, 0], ids=["reduced_form", "augmented_form"])
@@ -302,6 +314,16 @@ def test_factor_to_boundary_parity(bh):
         wl = np.where(rng.random(n) < 0.5, -np.inf, -1.0)
         wu = np.where(rng.random(n) < 0.5, np.inf, 1.0)
         assert bh.factor_to_boundary(p, w, wl, wu) == R.factor_to_boundary(p, w, wl, wu)
+    # NaN operands propagate like Julia's min (src/basic_tralcnlss.jl:803,805): NaN in w, Inf - Inf, NaN in p (fails both guards: skipped)
+    nan = np.nan
+    for p, w, wl, wu in ((np.array([1.0, -1.0, 2.0]), np.array([nan, 0.0, 0.0]), -np.ones(3), np.ones(3)),
+                         (np.array([-1.0, 1.0]), np.array([nan, 0.0]), -np.ones(2), np.ones(2)),
+                         (np.array([1.0]), np.array([np.inf]), np.array([-1.0]), np.array([np.inf])),
+                         (np.array([nan, 1.0]), np.array([0.0, 0.0]), -np.ones(2), np.ones(2)),
+                         (np.array([1e-11, 1.0]), np.array([nan, 0.0]), -np.ones(2), np.ones(2))):
+        dev, ref = bh.factor_to_boundary(p, w, wl, wu), R.factor_to_boundary(p, w, wl, wu)
+        assert (np.isnan(dev) and np.isnan(ref)) or dev == ref, (p, w, dev, ref)
+    assert np.isnan(bh.factor_to_boundary(np.array([1.0, -1.0, 2.0]), np.array([nan, 0.0, 0.0]), -np.ones(3), np.ones(3)))
     z = np.zeros(8)
     assert bh.factor_to_boundary(z, z, -np.ones(8), np.ones(8)) == np.inf
     assert bh.factor_to_boundary(np.array([-1.0]), np.array([0.0]), np.array([-np.inf]), np.array([np.inf])) == np.inf
@@ -345,7 +367,7 @@ def test_pcg_golden_fixtures(bh, cg_fused):
         if c["name"] == "maxiter_exhaust":
             tol = 1e-6      # 8 of its 14 iterations run on rounding noise (kappa2 = 0); only status/iters are pinned tightly
         if np.all(np.isfinite(w_ref)):
-            assert np.linalg.norm(w - w_ref) <= tol * max(np.linalg.norm(w_ref), 1e-300), (c["name"], relnorm(w, w_ref), tol)
+            assert_w_close(w, w_ref, tol, "golden fixtures: w", c["name"])
         else:
             assert np.array_equal(np.isnan(w), np.isnan(w_ref)) and np.array_equal(w[np.isfinite(w_ref)], w_ref[np.isfinite(w_ref)])
         tr_ref = np.array([[float(x) for x in row] for row in c["trace"]]).reshape(-1, 4)
@@ -354,7 +376,12 @@ def test_pcg_golden_fixtures(bh, cg_fused):
         if c["name"] != "maxiter_exhaust" and tr.size:
             m = np.isfinite(tr_ref)
             assert np.array_equal(np.isnan(tr), np.isnan(tr_ref)), c["name"]
-            np.testing.assert_allclose(tr[m], tr_ref[m], rtol=1e-6, atol=1e-10)
+            # SURVEY.md §8c asks 1e-9 for the scalar trace; the scalars of late iterations inherit the instance's own rounding
+            # sensitivity (the same `tol` as for w: max(1e-9, 20 x what the ORACLE's w moves under long-double accumulation))
+            rt = max(1e-9, tol)
+            err = np.abs(tr[m] - tr_ref[m]) / (1e-10 / rt + np.abs(tr_ref[m]))
+            note_tol("golden fixtures: scalar trace (rtol max(1e-9, case tolerance))", float(err.max()), rt, c["name"])
+            np.testing.assert_allclose(tr[m], tr_ref[m], rtol=rt, atol=1e-10)
         H.close()
         cons.close()
 
@@ -380,8 +407,8 @@ def test_pcg_random_instances(bh, cg_fused, d, n, q, mA, nfix, seed):
     cons = bh.MixedConstraints(A, cons_o.chol_L, fix)
     w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
     assert int(status) == int(s_ref) and info["iters"] == it_ref
-    tol = w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
-    assert relnorm(w, w_ref) <= tol, (relnorm(w, w_ref), tol)
+    assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))",
+                   "random instance d=%d n=%d q=%d mA=%d" % (d, n, q, mA))
     # w stays in the null space of the active constraints (src/basic_tralcnlss.jl:681-684)
     if mA:
         assert np.linalg.norm(A @ w) <= 1e-9 * np.linalg.norm(A) * np.linalg.norm(w)
@@ -411,7 +438,7 @@ def test_pcg_wide_rows_every_kernel_geometry(bh, cg_fused, d, n, nfix, kappa2):
     cons = bh.MixedConstraints(A, None, fix)
     w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, kappa2, trace_cap=32, full_output=True)
     assert int(status) == int(s_ref) and info["iters"] == it_ref and info["n_hmul"] == tr.n_hmul, (status, info["iters"], s_ref, it_ref)
-    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, kappa2, w_ref), relnorm(w, w_ref)
+    assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, kappa2, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
     k = min(len(tr.rows), 32)
     ref_rows = np.array(tr.rows[:k])
     m = np.isfinite(ref_rows)
@@ -444,7 +471,7 @@ def test_pcg_tall_narrow_more_workgroups_than_columns(bh, cg_fused, d, n, nfix):
         for _ in range(2):
             w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 1e-3, full_output=True)
             assert int(status) == int(s_ref) and info["iters"] == it_ref, (trial, status, info["iters"], s_ref, it_ref)
-            assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 1e-3, w_ref), relnorm(w, w_ref)
+            assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 1e-3, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
     H.close()
 
 
@@ -463,7 +490,7 @@ def test_pcg_config5_shape_linear_constraints(bh, proj_form, cg_fused):
     cons = bh.MixedConstraints(A, cons_o.chol_L, inst.fixvars)
     w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.01, full_output=True)
     assert int(status) == int(s_ref) and info["iters"] == it_ref
-    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.01, w_ref)
+    assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.01, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
     assert np.linalg.norm(A @ w) <= 1e-10 * np.linalg.norm(A) * np.linalg.norm(w)
 
 
@@ -483,7 +510,7 @@ def test_pcg_config2_synthetic_box(bh):
     cons = bh.MixedConstraints(A, None, inst.fixvars, l=inst.x_l, u=inst.x_u)
     w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
     assert int(status) == int(s_ref) and info["iters"] == it_ref
-    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+    assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
     # Ill-conditioned variant (columns scaled by 10^(-3j/n), cond(J'J) ~ 1e6): hundreds of iterations.  Finite-precision
     # CG is chaotic here: the ORACLE itself takes 406 / 451 / 465 iterations and moves w by 13-18 % when J@v is summed
     # in F-order, C-order or 1024-row chunks (measured in this container), so iteration-level parity is not defined.
@@ -498,7 +525,11 @@ def test_pcg_config2_synthetic_box(bh):
     Hic = bh.AlHessian.synthetic(d, n, seed=1, colscale=scale, mu=10.0)
     w, status, info = bh.projected_cg(gic, Hic, w_l, w_u, cons, 1e-3, full_output=True)
     assert int(status) == int(s_ref) == 0
-    assert 0.7 * it_ref <= info["iters"] <= 1.4 * it_ref, (info["iters"], it_ref)
+    # the oracle under re-association of its own H*p (the BLAS-backed variants only: long double takes minutes at this size)
+    band = oracle_iteration_band(gic, Hic_o, w_l, w_u, cons_o, 1e-3, variants=("reference", "C-order sums", "1024-row chunks", "rows reversed", "3 row blocks"))
+    print("[config 2, ill-conditioned] device %d iterations; oracle: %s" % (info["iters"], band))
+    assert all(st == 0 for st, _ in band.values())
+    assert_iters_in_oracle_band(info["iters"], band, "ill-conditioned CG: iteration count vs the oracle's own band", "config 2 ic")
     res = np.where(inst.fixvars, 0.0, R.hmul(Hic_o, w) + gic)
     v0 = np.where(inst.fixvars, 0.0, gic)
     assert abs(res @ res) < 1e-3 * np.linalg.norm(v0) * 1.001
@@ -771,7 +802,7 @@ def test_workspace_reuse_across_sizes_and_odd_n(bh, cg_fused):
         cons = bh.MixedConstraints(A, cons_o.chol_L, fix)
         w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
         assert int(status) == int(s_ref) and info["iters"] == it_ref, (n, mA)
-        assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), (n, mA)
+        assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
 
 
 # ----------------------------------------------------------------------------- callers on the device (a9, a10, f-2)
@@ -815,7 +846,7 @@ def test_minor_iterate_linesearch_gradient_parity(bh, d, n, q, mA, nfix, seed):
     w_cg, s_cg, it_cg = R.projected_cg(gm_ref, Ho, wl2, wu2, cons_o, 0.1)
     assert info["iters"] == it_cg
     tol = w_tolerance(gm_ref, Ho, wl2, wu2, cons_o, 0.1, w_cg)
-    assert relnorm(w, w_ref) <= 10 * tol, (relnorm(w, w_ref), tol)
+    assert_w_close(w, w_ref, 10 * tol, "minor_iterate: scaled w vs oracle (10 x the CG tolerance: alpha inherits w's sensitivity)")
     if int(st_ref) != int(R.CGStatus.negative_curvature):
         a_cg = R.linesearch(gm_ref, Ho, w_cg, wl2, wu2, cons_o.fixvars)
         # alpha = -g.w / w'Hw inherits the rounding sensitivity of w (tol, measured on the oracle itself)
@@ -955,7 +986,7 @@ def test_wide_jacobian_column_panels(bh, d, n, q):
     cons = bh.MixedConstraints(A, None, fix)
     w, status, info = bh.projected_cg(g, H, w_l, w_u, cons, 0.1, full_output=True)
     assert int(status) == int(s_ref) and info["iters"] == it_ref
-    assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+    assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
 
 
 def test_config4_sized_shard_on_one_gpu(bh):
@@ -1112,7 +1143,7 @@ def test_asynchronous_jacobian_ingest(bh, d, n, q, chunk_mb):
             w_ref, st_ref, it_ref = R.projected_cg(g, Ho, w_l, w_u, cons_o, 0.1)
             w, st, info = bh.projected_cg(g, H, w_l, w_u, bh.MixedConstraints(A, None, fix), 0.1, full_output=True)
             assert int(st) == int(st_ref) and info["iters"] == it_ref
-            assert relnorm(w, w_ref) <= w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref)
+            assert_w_close(w, w_ref, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref), "projected_cg: w vs oracle (tolerance max(1e-9, 20 x oracle sensitivity))")
     finally:
         bh.set_option("upload_chunk_mb", 64)
 
@@ -1337,7 +1368,8 @@ def test_device_pointer_calls_stay_inside_the_callers_buffers(bh, cg_fused, n, m
     for k in ("w", "w2", "t", "gm", "pv", "u", "jt", "gr"):
         assert np.all(np.isfinite(get(k))), k
     tol = max(1e-8, w_tolerance(g, Ho, w_l, w_u, cons_o, 0.1, w_ref))
-    assert relnorm(get("w"), w_ref) <= tol and relnorm(get("w2"), w2_ref) <= tol
+    assert_w_close(get("w"), w_ref, tol, "device-pointer calls: w vs oracle (max(1e-8, CG tolerance))")
+    assert_w_close(get("w2"), w2_ref, tol, "device-pointer calls: w vs oracle (max(1e-8, CG tolerance))")
     assert relnorm(get("t"), R.hmul(Ho, g)) <= 1e-12 and relnorm(get("u"), J @ g) <= 1e-12 and relnorm(get("jt"), g) <= 1e-12 and relnorm(get("gr"), g) <= 1e-12
     assert relnorm(get("pv"), R.projection(cons_o, g)) <= 1e-9
     assert ls == pytest.approx(R.linesearch(g, Ho, get("w"), w_l, w_u, cons_o.fixvars), rel=1e-9)
