@@ -70,11 +70,14 @@ def setup_instance(bh, rank, world, kind, d_per_gpu=D_PER_GPU, n=N_COLS, strong=
     return H, cons, dv, dict(g=g, w_l=w_l, w_u=w_u, x=x, x_l=x_l, x_u=x_u, fix=fix, lo=lo, hi=hi, d_total=d_total)
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json,
-    produced by tools/profile_round.sh + tools/summarize_profile.py; gfx950 FETCH_SIZE half-count already corrected)."""
+def pmc_traffic(config=3):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json, or
+    rNN_config5_pmc_traffic.json for --config 5; produced by tools/profile_round.sh + tools/summarize_profile.py; gfx950
+    FETCH_SIZE half-count already corrected)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    import re
+    pat = r"r\d+_pmc_traffic\.json$" if config == 3 else r"r\d+_config%d_pmc_traffic\.json$" % config
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if re.search(pat, os.path.basename(f)))
     if not files:
         return None, None
     data = json.load(open(files[-1]))
@@ -463,7 +466,7 @@ def main():
         dense = None
     bh.set_option("profile_stride", timed_stride)
 
-    traffic, traffic_src = pmc_traffic() if world == 1 else (None, None)
+    traffic, traffic_src = pmc_traffic(args.config) if world == 1 else (None, None)
     ms_per_step = 1e3 * elapsed / args.steps
     hmul_ms = st["hmul_ms"] / max(st["hmul_timed"], 1)
     achieved = st["bytes_per_hmul"] / (hmul_ms * 1e-3) / 1e9 if hmul_ms > 0 else 0.0
