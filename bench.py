@@ -402,7 +402,7 @@ def main():
     status, iters, n_hmul = out
     def replica_check(it_, nh_):
         """Lock-step check (outside the timed region): w is replicated state, every rank must hold the SAME BITS — the
-        launch-ahead schedule relies on it (DESIGN.md §6).  Compares a checksum of the bit patterns across ranks; returns
+        launch-ahead schedule relies on it (DESIGN.md §7).  Compares a checksum of the bit patterns across ranks; returns
         (identical, this rank's w)."""
         w_host = dv["w"].download()
         bits = w_host.view(np.uint64)

@@ -2098,14 +2098,13 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // H*p launch forms p on the fly and takes the exit test, one 128-workgroup kernel reduces the slabs and updates w, r, v.
     // (g doubles as the first H*p input, so it must be readable up to the padded length: workspace copy or n == ld.)
     const int rs_cfg = multi_panel(H) ? -1 : pick_config(H->nchunks);
-    // General constraints in the reduced projection form with mA <= 64 get the same treatment in FOUR kernels instead of seven:
-    // H*p (p formed on the fly), reduce/update leaving partials of A_free r, the small triangular solve (summing those partials),
-    // and left_mul_tr forming v = P(r) with its partials of r.v.
-    // (opt-in, cg_fused = 2: measured at config 5 it buys 0-2 % — the 64-step triangular solve and the single-workgroup kernels
-    // around it stay latency-bound — and it changes pHp's rounding like the box form does)
-    // Default (cg_fused = 1): THREE kernels — the triangular solves are replaced by two 64-term dot products per entry with the
-    // explicit inverse of the factor (tri_inv_small_kernel, rebuilt only when the factor changed), which every workgroup of the
-    // kernel that forms v = P(r) repeats for itself: H*p, reduce/update, project (proj_apply_linv_kernel).
+    // General constraints in the reduced projection form with mA <= 64 get the same treatment.
+    // Default (cg_fused = 1): THREE kernels instead of seven — H*p (p formed on the fly), reduce/update leaving partials of A_free r,
+    // and proj_apply_linv_kernel, whose every workgroup sums those partials and applies the explicit inverse of the factor
+    // (tri_inv_small_kernel, rebuilt only when the factor changed: two 64-term dot products per entry instead of the
+    // single-workgroup 128-step triangular solve) before forming its chunks of v = P(r) and its partial of r.v.
+    // cg_fused = 2: FOUR kernels — the triangular solves in a launch of their own (trsv_small_kernel summing the partials),
+    // then left_mul_tr.  Both change pHp's rounding like the box form does (cg_fused = 0 keeps dot(p, H*p)).
     const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 1 && P->reduced && P->mA <= 64 && P->tpart != nullptr && P->ldA == H->ld;
     const bool gen_linv = fuse_gen && g_ctx.opt_cg_fused == 1 && P->W != nullptr;
     // Several ranks: the two-kernel form carries the exchange inside the update kernel when the peer-buffer transport is the

@@ -17,7 +17,7 @@ namespace bh {
 // ------------------------------------------------------------------------------------------
 enum { MODE_JV = 0, MODE_JTV = 1, MODE_FUSED = 2 };
 
-// Two-kernel box-constrained CG iteration ("Device-resident CG"): the H*p launch of iteration j forms p_j itself
+// Two-kernel box-constrained CG iteration: the H*p launch of iteration j forms p_j itself
 // (CGP = 1) from what cg_reduce_update_kernel(j-1) left behind, and decides the loop's exit test on the way in.
 struct CgFuse {
     CgState* st;

@@ -317,7 +317,7 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        poll instead of hipStreamSynchronize (bh_pcg 0.660 -> 0.652 ms, bh_minor_iterate 0.693 -> 0.665 ms,
  *                        bh_project 31 -> 21 us on the config-3 instance); 0 = DMA + synchronize (round 1)
  *   "mailbox_flush"  [0] experiment: end the host-pointer entry points with a mailbox seal + poll instead of
- *                        hipStreamSynchronize (measured slower behind a D2H DMA)
+ *                        hipStreamSynchronize (measured slower behind a D2H DMA; docs/design_history_r1_r2.md §4)
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = for mA > 64 only: rank-one downdate of the factor itself (O(mA^2)), rebuilt from

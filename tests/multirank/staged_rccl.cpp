@@ -7,7 +7,7 @@
 //     drain the stream -> D2H into slot[rank] -> barrier -> sum the slots in RANK ORDER -> H2D -> barrier.
 // Every rank adds the slots in the same order, so the result is bit-identical on all ranks (what RCCL guarantees).
 // A rank that waits longer than 60 s for its peers returns ncclSystemError: a launch-schedule mismatch between ranks
-// (the hazard DESIGN.md §6 describes) fails the test instead of hanging it.
+// (the hazard DESIGN.md §7 describes) fails the test instead of hanging it.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 

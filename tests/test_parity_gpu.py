@@ -676,7 +676,7 @@ def test_one_rank_communicator_paths(comm, capsys):
     """Both transports of the all-reduce with a 1-rank communicator in a child process (BH_FORCE_COMM=1) — RCCL: dlopen,
     ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on the library stream; peer buffers: inbox, hipIpc-free self exchange
     through the fused reduce+exchange kernel — results must equal the communicator-free run bit for bit; prints what one
-    all-reduce of an n-vector costs on each path (bh_time_kernel kinds 7 / 8; quoted in DESIGN.md §6)."""
+    all-reduce of an n-vector costs on each path (bh_time_kernel kinds 7 / 8; quoted in docs/design_history_r1_r2.md §6)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

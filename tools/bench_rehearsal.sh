@@ -21,8 +21,13 @@ for cfg in "2 weak ipc" "3 strong ipc" "2 weak both" "2 weak both fault"; do
             -o tests/multirank/libstaged_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -Wl,-rpath,/opt/rocm/lib || exit 1
         export BH_RCCL_LIB=$R/tests/multirank/libstaged_rccl.so BH_STAGED_RCCL_SHM=/bh_rehearsal_$$
     fi
-    timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port 2953$1 \
-        bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2_$3$4.log 2>&1 || rc=$?
+    if [ "$3" = "ipc" ]; then
+        # as typed, without a launcher: bench.py starts its ranks itself (child processes; the launcher never touches HIP)
+        timeout -k 10 400 python bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2_$3$4.log 2>&1 || rc=$?
+    else
+        timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port 2953$1 \
+            bench.py --gpus $1 --steps 20 --warmup 2 --scaling $2 > gpurun_out/bench_rehearsal_$1_$2_$3$4.log 2>&1 || rc=$?
+    fi
     rm -f /dev/shm/bh_rehearsal_$$
     tail -1 gpurun_out/bench_rehearsal_$1_$2_$3$4.log | cut -c1-1200
     grep -o '"comm": {[^}]*}[^}]*}' gpurun_out/bench_rehearsal_$1_$2_$3$4.log | cut -c1-900

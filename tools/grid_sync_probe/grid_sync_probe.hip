@@ -1,5 +1,5 @@
 // grid_sync_probe.hip — what does one grid-wide barrier cost on this device (cooperative launch, one workgroup per CU)?
-// Input for the "one cooperative kernel per CG iteration" idea in DESIGN.md §7: such a kernel needs 3 barriers per iteration.
+// Input for the "one cooperative kernel per CG iteration" idea in DESIGN.md §5 (docs/design_history_r1_r2.md §7): such a kernel needs 3 barriers per iteration.
 //   hipcc --offload-arch=gfx950 -O3 -o grid_sync_probe grid_sync_probe.hip && ./grid_sync_probe
 #include <hip/hip_runtime.h>
 #include <hip/hip_cooperative_groups.h>
