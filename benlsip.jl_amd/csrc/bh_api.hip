@@ -36,6 +36,7 @@ struct CgWorkspace {
     double *x = nullptr, *s = nullptr, *xlow = nullptr, *xupp = nullptr;   // minor_iterate staging
     double* hw = nullptr;          // H*w accumulated by the CG loop for minor_iterate's linesearch
     double *p2 = nullptr, *gpart = nullptr, *rvpart = nullptr;   // two-kernel box iteration: p ping-pong, (spare), r.v partials (2 x n_pad/2)
+    double *r2 = nullptr, *hpx = nullptr, *hpx_tail = nullptr;   // RCCL form of it: r ping-pong; H*p with the p'Hp slot right behind it (hpx[n_pad] = hpx_tail[0])
     double* slab = nullptr;
     double* scalars = nullptr;     // 8 doubles (linesearch alpha, ...)
     CgState* d_state = nullptr;
@@ -308,6 +309,19 @@ void launch_row_stream(int cfg, int mode, const RowStreamArgs& a, int grid, hipS
     }
 }
 
+// CGP = 3: the RCCL form (update of the previous iteration folded into the prologue); register-resident geometries only.
+bool cgp3_supported(int cfg) { return cfg <= 5; }
+void launch_row_stream_cgp3(int cfg, const RowStreamArgs& a, int grid, hipStream_t s) {
+    switch (cfg) {
+        case 0: hipLaunchKernelGGL((row_stream_kernel<64, 1, 8, MODE_FUSED, 1, 1, 0, 3>), dim3(grid), dim3(64), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((row_stream_kernel<256, 1, 8, MODE_FUSED, 1, 1, 0, 3>), dim3(grid), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((row_stream_kernel<256, 2, 8, MODE_FUSED, 1, 1, 0, 3>), dim3(grid), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((row_stream_kernel<256, 4, 4, MODE_FUSED, 1, 1, 0, 3>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((row_stream_kernel<256, 8, 4, MODE_FUSED, 1, 1, 0, 3>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((row_stream_kernel<512, 8, 2, MODE_FUSED, 1, 1, 0, 3>), dim3(grid), dim3(512), 0, s, a); break;
+    }
+}
+
 bool cgp_supported(int cfg) { return cfg <= 5 || cfg == 14; }
 void launch_row_stream_cgp(int cfg, const RowStreamArgs& a, int grid, hipStream_t s, bool expect_stop) {
     switch (cfg) {
@@ -412,8 +426,9 @@ int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
     CgWorkspace& c = g_ctx.cg;
     if (c.n_pad < n_pad) {
         // order matters: the host-pointer entry points stage (g, wl, wu), (s, x, xlow, xupp, g) or (x, xlow, xupp, g) with ONE DMA
-        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.s, &c.x, &c.xlow, &c.xupp, &c.g, &c.wl, &c.wu, &c.hw, &c.p2, &c.gpart, &c.rvpart};
-        constexpr int NV = 16;
+        double** vecs[] = {&c.w, &c.r, &c.v, &c.p, &c.Hp, &c.s, &c.x, &c.xlow, &c.xupp, &c.g, &c.wl, &c.wu, &c.hw, &c.p2, &c.gpart, &c.rvpart,
+                           &c.r2, &c.hpx, &c.hpx_tail};
+        constexpr int NV = 19;
         dev_free(c.slab);
         c.slab = nullptr;
         BH_TRY(dev_alloc(&c.slab, NV * n_pad + 8));
@@ -679,7 +694,9 @@ int32_t alloc_hess_common(bh_hess* H) {
     int64_t gmax = (int64_t)g_ctx.n_cu * kMaxBlocksPerCu;
     H->g_cap = (int)gmax;
     BH_TRY(dev_alloc(&H->partials, gmax * H->ld));
-    BH_TRY(dev_alloc(&H->sq_partials, 2 * gmax));      // [0, gmax): sum w (Jp)^2 per workgroup; [gmax, 2 gmax): its factor_to_boundary minimum
+    // [0, gmax): sum w (Jp)^2 per workgroup; [gmax, 2 gmax): its factor_to_boundary minimum; [2 gmax, 3 gmax): the same, ping-pong
+    // partner for the RCCL form of the two-kernel iteration (there the H*p launch reads the previous launch's minima itself)
+    BH_TRY(dev_alloc(&H->sq_partials, 3 * gmax));
     BH_TRY(dev_alloc(&H->scalar, 2));
     H->stats.bytes_per_hmul = (multi_panel(H) ? 16.0 : 8.0) * (double)(H->d + H->q_eff) * (double)H->n + 16.0 * (double)H->n;
     return BH_OK;
@@ -2230,6 +2247,82 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         // exchanges that really ran (one per executed H*p): how many update kernels were ENQUEUED past the exit depends on when
         // this rank polled its progress word, and those exchange nothing
         if (peer_fused) H->stats.n_allreduce += mw.n_hmul;
+        return BH_OK;
+    }
+    // Several ranks over RCCL, box constraints: TWO kernels and the collective per iteration.  An ncclAllReduce is
+    // enqueued by the host, so it cannot sit inside the update kernel as the peer-buffer exchange does; instead the update of
+    // iteration j-1 moves into the prologue of the H*p launch of iteration j (row_stream_kernel<..., CGP = 3>: every workgroup
+    // redoes it for the whole 32 KiB vector, the owners of a chunk store it), and the slab reduction packs this rank's share of
+    // p'Hp behind the vector that goes through the all-reduce:  S(1) | R(1) AR(1) S(2) | R(2) AR(2) S(3) | ...
+    // The launch schedule is the lock-step one of the three-kernel form below (decisions on "done by iteration k" only).
+    const bool rccl_fused = comm_active() && !use_peer_path() && box && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp3_supported(rs_cfg) &&
+                            max_iter >= 1 && (gp == c.g || n == n_pad);
+    if (rccl_fused) {
+        BH_TRY(hess_ready(H));
+        if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
+        const int64_t nrows = H->d + H->q_eff;
+        const int grid = grid_for(rs_cfg, nrows);
+        const int nblk = (H->nchunks + 15) / 16;
+        double* pbuf[2] = {c.p, c.p2};
+        double* rbuf[2] = {c.r, c.r2};
+        double* gbuf[2] = {H->sq_partials + H->g_cap, H->sq_partials + 2 * (int64_t)H->g_cap};       // gamma partials, one per workgroup
+        auto launch_stream = [&](int j) -> int32_t {
+            RowStreamArgs ra = rs_args(H, nrows, nullptr);
+            ra.partials = H->partials;
+            ra.v = gp; ra.negate = 1; ra.negmask = a.fixrank;                // j == 1: p_1 = -mask(g), formed on the fly
+            CgFuse& f = ra.cf;
+            f.st = c.d_state; f.j = j; f.n = (int)n; f.max_iter = max_iter; f.init_done = 0;
+            f.p_old = pbuf[(j - 1) & 1]; f.p_new = pbuf[j & 1];
+            f.r_old = rbuf[(j - 1) & 1]; f.r_new = rbuf[j & 1];
+            f.gpart_in = gbuf[(j - 1) & 1]; f.gpart = gbuf[j & 1];
+            f.w_rw = wp; f.w = wp; f.hw = hw; f.g = gp; f.fixrank = a.fixrank;
+            f.wl = wlp; f.wu = wup;
+            f.sqpart = H->sq_partials;
+            f.Hp = c.hpx; f.sq_index = (int)n_pad;
+            f.kappa2 = kappa2; f.atol_f2b = atol_f2b; f.atol_neg = atol_negcurv;
+            f.trace = a.trace; f.trace_cap = a.trace_cap; f.mirror = a.mirror; f.tag = a.tag;
+            int slot = -1;
+            BH_TRY(profile_begin(H, j - 1, &slot));
+            launch_row_stream_cgp3(rs_cfg, ra, grid, s);
+            if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], s));
+            return BH_OK;
+        };
+        auto launch_iteration = [&](int index) -> int32_t {                 // index = j - 1: R(j), AR(j), S(j + 1)
+            const int j = index + 1;
+            hipLaunchKernelGGL(reduce_partials_sq_kernel, dim3(nblk), dim3(256), 0, s, (const double*)H->partials, H->ld, H->nchunks, grid,
+                               c.hpx, (const double*)H->sq_partials, (int)n_pad, (const CgState*)c.d_state, j);
+            BH_HIP(hipGetLastError());
+            BH_TRY(allreduce_inplace(c.hpx, n_pad + 2, H));
+            return launch_stream(j + 1);
+        };
+        BH_TRY(launch_stream(1));
+        const int batch = launch_batch_size(H);
+        int launched = 0;
+        auto launch_batch = [&](int nb) -> int32_t {
+            nb = std::min(nb, max_iter - launched);
+            for (int i = 0; i < nb; ++i) BH_TRY(launch_iteration(launched + i));
+            launched += nb;
+            return BH_OK;
+        };
+        MirrorWord mw{};
+        auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
+        const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : 1;
+        BH_TRY(launch_batch(first));
+        BH_TRY(wait_mirror(c, a.tag, launched, &mw));
+        if (!done_by(launched) && launched < max_iter) {
+            BH_TRY(launch_batch(batch));
+            while (true) {
+                const int target = launched;
+                const bool more = launched < max_iter;
+                if (more) BH_TRY(launch_batch(batch));
+                BH_TRY(wait_mirror(c, a.tag, target, &mw));
+                if (done_by(target) || !more) break;
+            }
+        }
+        BH_TRY(wait_mirror(c, a.tag, launched, &mw));
+        if (!mw.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
+        fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
+        fin_out->tag = a.tag;
         return BH_OK;
     }
     // Box constraints with register-resident vectors: no init kernel — the first H*p forms p0 = -mask(g) on the fly and

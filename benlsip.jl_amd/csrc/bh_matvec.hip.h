@@ -38,6 +38,19 @@ struct CgFuse {
     double kappa2, atol_f2b;
     double* trace; int trace_cap;
     unsigned long long* mirror; unsigned tag;
+    // CGP = 3 (several ranks over RCCL: two kernels + the collective per iteration): the launch of iteration j ALSO performs the
+    // vector update of iteration j-1 (:725-748) that cg_reduce_update_kernel does on one rank — every workgroup for the whole
+    // vector, redundantly (the vectors are 32 KiB: L2 hits), so that no kernel stands between the all-reduce and the next H*p
+    const double* gpart_in; // the gamma partials the launch of iteration j-1 left (ping-pong with gpart: this launch writes the other one)
+    const double* Hp;       // all-reduced H*p of iteration j-1 (ld doubles) followed by the all-reduced p'Hp at [sq_index]
+    int sq_index;
+    const double* r_old;    // r before the update of iteration j-1   (ping-pong: everybody reads it, the owners write r_new)
+    double* r_new;
+    double* w_rw;           // w, updated in place by the workgroup that owns the chunk (nobody else reads it)
+    double* hw;             // H*w accumulated next to w, or NULL
+    const double* g;        // j == 1: r_1 = g_minor (:705)
+    const int* fixrank;     // v = mask(r)
+    double atol_neg;
 };
 
 struct RowStreamArgs {
@@ -75,7 +88,9 @@ struct RowStreamArgs {
 template <int T, int CPT, int R, int MODE, int NT = 1, int PF = 1, int VL = 0, int CGP = 0>
 __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
     if (!CGP && a.state != nullptr && a.state->done) return;
-    if (CGP && a.cf.j > 1 && a.cf.st->stop_at != 0 && a.cf.j > a.cf.st->stop_at) return;   // the loop stopped before this iteration
+    // the loop stopped before this iteration (CGP = 3: the launch that FINDS the stop is j = stop_at + 1 and writes stop_at itself —
+    // every one of its workgroups must still get through its prologue, whose owner stores complete w)
+    if (CGP && a.cf.j > 1 && a.cf.st->stop_at != 0 && a.cf.j > a.cf.st->stop_at + (CGP == 3 ? 1 : 0)) return;
     constexpr int NW = T / 64;
     __shared__ double red[2][R][NW];
     __shared__ double pro[2][NW];                                       // CGP, iteration 1, workgroup 0 only
@@ -211,7 +226,183 @@ __global__ __launch_bounds__(T) void row_stream_kernel(RowStreamArgs a) {
             }
         }
     }
-    if (CGP) {
+    if (CGP == 3) {
+        // ---- several ranks over RCCL: update of iteration j-1 + exit test + p_j, every workgroup for the whole vector -------------
+        const CgFuse& f = a.cf;
+        CgState* st = f.st;
+        const double QNAN = __longlong_as_double(0x7ff8000000000000ll);
+        OpMinNan opmin;
+        double2 wnew[CPT];                       // w after the update, for the chunks this workgroup owns (factor_to_boundary below)
+        bool own[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = tid + k * T;
+            own[k] = act[k] && ((c / CPT) % (int)G) == (int)blockIdx.x;
+            wnew[k] = make_double2(0.0, 0.0);
+        }
+        if (f.j == 1) {
+            // :702-718: vv = -mask(g) was formed above; r_1 = g and w = 0 are stored by the owners, CgState is set by workgroup 0
+            double rtv0 = 0.0;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) { rtv0 = fma(vv[k].x, vv[k].x, rtv0); rtv0 = fma(vv[k].y, vv[k].y, rtv0); }
+            rtv0 = wave_sum(rtv0);
+            if (lane == 0) pro[0][wave] = rtv0;
+            __syncthreads();
+            double t = 0.0;
+            for (int w2 = 0; w2 < NW; ++w2) t += pro[0][w2];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                if (!own[k]) continue;
+                const int c = tid + k * T;
+                double2 gk = reinterpret_cast<const double2*>(f.g)[c];
+                if (2 * c >= f.n) gk.x = 0.0;
+                if (2 * c + 1 >= f.n) gk.y = 0.0;
+                reinterpret_cast<double2*>(f.r_new)[c] = gk;
+                reinterpret_cast<double2*>(f.w_rw)[c] = make_double2(0.0, 0.0);
+                if (f.hw != nullptr) reinterpret_cast<double2*>(f.hw)[c] = make_double2(0.0, 0.0);
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                st->rtv = t; st->rtv_pp[0] = t; st->rtv_pp[1] = 0.0;
+                st->tol_cg = f.kappa2 * sqrt(t);
+                st->pHp = 0.0; st->alpha = 0.0; st->gamma = 0.0; st->beta = 0.0;
+                st->iter = 1; st->max_iter = f.max_iter;
+                st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
+                st->n_hmul = 0; st->need_proj = 0; st->done = 0; st->status = 4; st->stop_at = 0;
+                tie_reset(st);
+            }
+            __syncthreads();                                   // pro[] is reused below
+        } else {
+            double2 hp[CPT], po[CPT], rk[CPT];
+            int2 fr[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                hp[k] = po[k] = rk[k] = make_double2(0.0, 0.0);
+                fr[k] = make_int2(-1, -1);
+                if (act[k]) {
+                    const int c = tid + k * T;
+                    hp[k] = reinterpret_cast<const double2*>(f.Hp)[c];
+                    po[k] = reinterpret_cast<const double2*>(f.p_old)[c];
+                    rk[k] = reinterpret_cast<const double2*>(f.r_old)[c];
+                    if (f.fixrank != nullptr) fr[k] = reinterpret_cast<const int2*>(f.fixrank)[c];
+                }
+            }
+            const double pHp = f.Hp[f.sq_index];                               // :723, summed over the ranks by the all-reduce
+            const double rtv = st->rtv_pp[f.j & 1], tol_cg = st->tol_cg;       // r.v entering iteration j-1
+            TieRegs tr;
+            tr.load(st);
+            const double gamma = wave_fixed_min(f.gpart_in, (int)G);           // :728 / :734, left by the launch of iteration j-1
+            int cont = 0, neg = 0, outside = 0;
+            double step = 0.0, alpha = QNAN;
+            bool add_w = true;
+            if (pHp <= f.atol_neg) {                        // :725
+                neg = 1;
+                if (fabs(pHp) > f.atol_neg) step = gamma;   // :727-729
+                else add_w = false;
+            } else {
+                alpha = __ddiv_rn(rtv, pHp);                // :733
+                outside = alpha > gamma;                    // :735
+                if (outside) step = gamma;                  // :737
+                else { step = alpha; cont = 1; }            // :739
+            }
+            // r += alpha Hp (:740), v = mask(r) (:741), r.v (:743) — the whole vector in every workgroup, same order everywhere
+            double part = 0.0;
+            double2 vk[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = tid + k * T;
+                vk[k] = make_double2(0.0, 0.0);
+                if (cont) {
+                    rk[k].x = __dadd_rn(rk[k].x, __dmul_rn(alpha, hp[k].x));
+                    rk[k].y = __dadd_rn(rk[k].y, __dmul_rn(alpha, hp[k].y));
+                    if (!act[k] || 2 * c >= f.n) rk[k].x = 0.0;               // padding stays exactly zero (Inf * 0 would poison it)
+                    if (!act[k] || 2 * c + 1 >= f.n) rk[k].y = 0.0;
+                    vk[k].x = (fr[k].x >= 0) ? 0.0 : rk[k].x;
+                    vk[k].y = (fr[k].y >= 0) ? 0.0 : rk[k].y;
+                    part = fma(rk[k].y, vk[k].y, fma(rk[k].x, vk[k].x, part));
+                }
+            }
+            part = wave_sum(part);
+            if (lane == 0) pro[0][wave] = part;
+            __syncthreads();
+            double rtv_next = 0.0;
+            for (int w2 = 0; w2 < NW; ++w2) rtv_next += pro[0][w2];
+            const bool solved = cont && fabs(rtv_next) < tol_cg;               // :747
+            const bool stop = !cont || solved || f.j > f.max_iter;             // :720 with iter = j after :748
+            const double beta = __ddiv_rn(rtv_next, rtv);                      // :744
+            // the owners store w (+= step p, :729 / :737 / :739), H*w and the new r
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                if (!own[k]) continue;
+                const int c = tid + k * T;
+                double2 wk = reinterpret_cast<const double2*>(f.w_rw)[c];
+                if (add_w) {
+                    wk.x = __dadd_rn(wk.x, __dmul_rn(step, po[k].x));
+                    wk.y = __dadd_rn(wk.y, __dmul_rn(step, po[k].y));
+                    if (2 * c >= f.n) wk.x = 0.0;
+                    if (2 * c + 1 >= f.n) wk.y = 0.0;
+                    reinterpret_cast<double2*>(f.w_rw)[c] = wk;
+                    if (f.hw != nullptr) {
+                        double2 hwk = reinterpret_cast<const double2*>(f.hw)[c];
+                        hwk.x = __dadd_rn(hwk.x, __dmul_rn(step, hp[k].x));
+                        hwk.y = __dadd_rn(hwk.y, __dmul_rn(step, hp[k].y));
+                        if (2 * c >= f.n) hwk.x = 0.0;
+                        if (2 * c + 1 >= f.n) hwk.y = 0.0;
+                        reinterpret_cast<double2*>(f.hw)[c] = hwk;
+                    }
+                }
+                wnew[k] = wk;
+                reinterpret_cast<double2*>(f.r_new)[c] = rk[k];
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                const int it = f.j - 1;                                        // the iteration being completed
+                tr.note_step_a(pHp, f.atol_neg, alpha, gamma, it);
+                if (cont) tr.note(TIE_TOL, rel_margin(fabs(rtv_next), tol_cg), it);
+                tr.store(st);
+                if (f.trace != nullptr && it <= f.trace_cap) {
+                    double* row = f.trace + 4 * (int64_t)(it - 1);
+                    row[0] = pHp; row[1] = alpha; row[2] = (neg && !add_w) ? QNAN : gamma; row[3] = cont ? rtv_next : rtv;
+                }
+                st->pHp = pHp; st->gamma = gamma; st->alpha = alpha; st->n_hmul = it; st->beta = beta;
+                st->neg_curvature = neg; st->outside_region = outside; st->need_proj = 0;
+                st->rtv = cont ? rtv_next : rtv; st->rtv_pp[(f.j - 1) & 1] = rtv_next;
+                st->iter = cont ? f.j : it;                                    // :748
+                int status = 4;
+                if (stop) {
+                    status = cont ? cg_status_of(solved ? 1 : 0, 0, 0, f.j, f.max_iter) : cg_status_of(0, outside, neg, it, f.max_iter);
+                    st->approx_solved = solved ? 1 : 0; st->done = 1; st->stop_at = it; st->status = status;
+                }
+                publish_word(f.mirror, f.tag, status, stop ? 1 : 0, cont ? f.j : it, it, tr);
+            }
+            if (stop) return;
+            if (PF && g < ngroups) load_group(A, g);                           // the stream starts here (no prefetch before the exit test)
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                vv[k].x = __dadd_rn(-vk[k].x, __dmul_rn(beta, po[k].x));       // :745
+                vv[k].y = __dadd_rn(-vk[k].y, __dmul_rn(beta, po[k].y));
+            }
+            __syncthreads();                                                   // pro[] is reused below
+        }
+        // the owners store p_j and fold their factor_to_boundary terms (:734 / :728) into this workgroup's partial of gamma
+        double gm = __longlong_as_double(0x7ff0000000000000ll);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            if (!own[k]) continue;
+            const int c = tid + k * T;
+            reinterpret_cast<double2*>(f.p_new)[c] = vv[k];
+            const double2 lo = reinterpret_cast<const double2*>(f.wl)[c], hi = reinterpret_cast<const double2*>(f.wu)[c];
+            if (2 * c < f.n) gm = opmin(gm, f2b_term(vv[k].x, wnew[k].x, lo.x, hi.x, f.atol_f2b));
+            if (2 * c + 1 < f.n) gm = opmin(gm, f2b_term(vv[k].y, wnew[k].y, lo.y, hi.y, f.atol_f2b));
+        }
+        gm = wave_min(gm);
+        if (NW > 1) {
+            if (lane == 0) pro[1][wave] = gm;
+            __syncthreads();
+            gm = pro[1][0];
+            for (int w2 = 1; w2 < NW; ++w2) gm = opmin(gm, pro[1][w2]);
+        }
+        if (tid == 0) f.gpart[blockIdx.x] = gm;
+    }
+    if (CGP && CGP != 3) {
         const CgFuse& f = a.cf;
         CgState* st = f.st;
         if (f.j == 1) {
@@ -380,6 +571,34 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const double* __re
         for (int r = 1; r < 16; ++r) { t.x += sm[r][cl].x; t.y += sm[r][cl].y; }
         reinterpret_cast<double2*>(out)[c] = t;
     }
+}
+
+// The same for the RCCL form of the two-kernel CG iteration: gated on CgState::stop_at, and block 0 also folds this rank's
+// partials of p'Hp (sum_i w_i (Jp)_i^2) into out[sq_index], the slot behind the vector that rides through the all-reduce.
+__global__ __launch_bounds__(256) void reduce_partials_sq_kernel(const double* __restrict__ partials, int64_t ld, int nchunks, int G,
+                                                                 double* __restrict__ out, const double* __restrict__ sqpart, int sq_index,
+                                                                 const CgState* st, int j) {
+    if (st->stop_at != 0 && j > st->stop_at) return;
+    __shared__ double2 sm[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int64_t ld2 = ld >> 1;
+    const double2* P2 = reinterpret_cast<const double2*>(partials);
+    const int cc = min(c, nchunks - 1);
+    SlabBatch sb;
+    sb.issue(P2, ld2, cc, rl, G);
+    double sq = 0.0;
+    if (blockIdx.x == 0) sq = wave_fixed_sum(sqpart, G);
+    const double2 acc = sb.fold(P2, ld2, cc, rl, G);
+    sm[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < nchunks) {
+        double2 t = sm[0][cl];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) { t.x += sm[r][cl].x; t.y += sm[r][cl].y; }
+        reinterpret_cast<double2*>(out)[c] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[sq_index] = sq; out[sq_index + 1] = 0.0; }
 }
 
 // Sum m doubles (single workgroup) into out[0]; used for the vthv scalar.

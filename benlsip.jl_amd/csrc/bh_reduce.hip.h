@@ -106,6 +106,9 @@ struct CgState {
     // iteration j > stop_at return at once; kernels of iteration j == stop_at never look at a word their own launch writes.
     int stop_at;
     int pad2;
+    // CGP = 3 (two-kernel iteration over RCCL): r.v after k updates at rtv_pp[k & 1] — the launch of iteration j reads the slot its
+    // own workgroup 0 does not write
+    double rtv_pp[2];
 };
 
 // Sum / min of m doubles by ONE wave in an order that does not depend on the workgroup shape: lane l folds x[l], x[l+64], ...

@@ -330,3 +330,18 @@ def test_advisor_r2_rank_invariant_iteration_shape_and_deferred_row_count(tmp_pa
     assert int(z[2]["b_rows"]) == 0
     assert float(z[0]["b_sq"]) == pytest.approx(float(r @ r), rel=1e-14)
     assert relnorm(z[0]["b_hv"], R.hmul(R.AlHessian(J, C, 2.0), gvec)) <= 1e-12
+
+
+def test_rccl_two_kernel_iteration_on_a_one_rank_communicator(capsys):
+    """over RCCL the box-constrained CG iteration is two kernels + the collective — the update of iteration j-1
+    lives in the prologue of the H*p launch of iteration j (row_stream_kernel<..., CGP = 3>), the slab reduction packs this rank's
+    p'Hp behind the vector that is all-reduced.  A 1-rank RCCL communicator (BH_FORCE_COMM=1: real librccl, real ncclAllReduce on
+    the library stream) runs every box case of the golden file (all exit statuses, traces) and random instances, also through
+    bh_minor_iterate, against the oracle; the multi-process runs of this file cover the same path over the staged stand-in."""
+    env = {k: v for k, v in os.environ.items() if k not in ("BH_RCCL_LIB",)}
+    env.update(BH_FORCE_COMM="1", BH_COMM="rccl")
+    out = subprocess.run([sys.executable, os.path.join(MR, "rccl_one_rank_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    with capsys.disabled():
+        print("[RCCL two-kernel iteration, 1-rank communicator] " + out.stdout.strip().splitlines()[-1])
+    assert out.stdout.strip().splitlines()[-1].startswith("OK")
