@@ -107,6 +107,10 @@ struct Ctx {
     int64_t opt_chol_downdate = 0;
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
+    // bh_step_accumulate_dev right behind the bh_minor_iterate_dev that produced its w: g_minor += H*w with the H*w that CG loop
+    // accumulated (scaled with w by the line search) instead of a fresh sweep H*s + g over J — one H-product less per minor iterate
+    int64_t opt_step_from_cg = 1;
+    struct { const void* H = nullptr; const double* w = nullptr; const double* gm = nullptr; } hw_note;   // what cg.hw currently is H*w of
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_final_sync = 0;      // *_dev: always drain the stream before returning (1), or only wait for what the host is owed (0)
     // the end-of-call wait of the host-pointer entry points: hipStreamSynchronize (0) or a mailbox seal + poll (1: A/B'd, SLOWER —
@@ -431,6 +435,7 @@ int32_t ensure_cg_workspace(int64_t n_pad, int64_t trace_cap) {
         constexpr int NV = 19;
         dev_free(c.slab);
         c.slab = nullptr;
+        g_ctx.hw_note = {};                      // cg.hw goes with the old slab
         BH_TRY(dev_alloc(&c.slab, NV * n_pad + 8));
         BH_HIP(hipMemsetAsync(c.slab, 0, (size_t)(NV * n_pad + 8) * sizeof(double), g_ctx.stream));
         for (int i = 0; i < NV; ++i) *vecs[i] = c.slab + (int64_t)i * n_pad;
@@ -1339,6 +1344,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "mailbox_flush")) { g_ctx.opt_mbox_flush = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "host_copy_kernels")) { g_ctx.opt_host_copy_kernels = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "ls_from_cg")) { g_ctx.opt_ls_from_cg = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "step_from_cg")) { g_ctx.opt_step_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
@@ -1778,6 +1784,7 @@ int32_t bh_hess_set_mu(bh_hess* H, double mu) {
 }
 
 int32_t bh_hess_destroy(bh_hess* H) {
+    if (H && g_ctx.hw_note.H == H) g_ctx.hw_note = {};
     if (!H) return BH_OK;
     if (H->up) {                              // an upload still in flight: let it finish before its buffers go
         AsyncUpload* u = H->up;
@@ -2099,6 +2106,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     H->ev_pending.clear();
     hipStream_t s = g_ctx.stream;
     const bool in_place = !w_in_ws;
+    if (hw != nullptr) g_ctx.hw_note = {};          // cg.hw is about to be overwritten
 
     CgArgs a{};
     a.st = c.d_state; a.w = wp; a.r = c.r; a.v = c.v; a.p = c.p; a.Hp = c.Hp; a.g = gp; a.wl = wlp; a.wu = wup;
@@ -2528,7 +2536,7 @@ int32_t bh_pcg_dev(bh_hess* H, bh_proj* P, const double* g_minor_dev, const doub
 // wHw = vthv(H, w_pad) -> H->scalar (all-reduced), then alpha -> c.scalars[0]; optionally w_pad *= alpha.
 // hw: H*w accumulated by the CG loop (then w'Hw = w.hw, no sweep over J), or NULL (then wHw = vthv(H, w): one J*v pass).
 static int32_t launch_linesearch(bh_hess* H, bh_proj* P, const double* g_dev, double* w_pad, const double* wl_dev, const double* wu_dev,
-                                 bool scale_w, const double* hw = nullptr, double* alpha_dst = nullptr /* default: c.scalars[0] */) {
+                                 bool scale_w, double* hw = nullptr, double* alpha_dst = nullptr /* default: c.scalars[0] */) {
     CgWorkspace& c = g_ctx.cg;
     if (hw == nullptr) {
         BH_TRY(launch_jv(H, w_pad, nullptr, true, H->scalar));
@@ -2640,6 +2648,8 @@ static int32_t minor_iterate_impl(bh_hess* H, bh_proj* P, const double* x, const
         BH_TRY(finish_device_call());
     }
     BH_TRY(pcg_finish(H, fin, !dev));
+    // cg.hw now holds H*w for the w just delivered (scaled with it by the line search): bh_step_accumulate_dev may use it
+    if (dev && hw != nullptr) { g_ctx.hw_note.H = H; g_ctx.hw_note.w = w_out; g_ctx.hw_note.gm = g_model; }
     if (status) *status = fin.status;
     if (iters) *iters = fin.iter;
     if (n_hmul_out) *n_hmul_out = fin.n_hmul;
@@ -2732,6 +2742,21 @@ int32_t bh_hmul_add_dev(bh_hess* H, const double* s_dev, const double* g_dev, do
 // s .+= w ; g_minor = H*s + g — src/basic_tralcnlss.jl:436-437, on device vectors (s is updated in place).
 int32_t bh_step_accumulate_dev(bh_hess* H, double* s_dev, const double* w_dev, const double* g_dev, double* g_minor_out_dev) {
     if (!w_dev || !s_dev) return fail(BH_ERR_INVALID_ARG, "NULL argument");
+    // The inner step's pattern (src/basic_tralcnlss.jl:434-437): g_minor_out holds H*s + g, it was the g_model of the
+    // bh_minor_iterate_dev that has just produced w, and that call's CG loop accumulated H*w.  Then H*(s + w) + g = g_minor + H*w:
+    // two n-vector kernels instead of a sweep over J.  Recognised by the three pointers; anything else recomputes H*s + g.
+    if (g_ctx.init && H && g_dev && g_minor_out_dev && g_ctx.opt_step_from_cg && g_ctx.hw_note.H == H && g_ctx.hw_note.w == w_dev &&
+        g_ctx.hw_note.gm == g_minor_out_dev && g_ctx.cg.hw != nullptr) {
+        g_ctx.hw_note = {};                          // one use: s changes below, a second call with the same w is a different step
+        const int64_t n = H->n;
+        const int grid = std::max(1, std::min((int)((n + 255) / 256), 1024));
+        hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)s_dev, w_dev, s_dev, (int)n);
+        hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)g_minor_out_dev, (const double*)g_ctx.cg.hw,
+                           g_minor_out_dev, (int)n);
+        BH_HIP(hipGetLastError());
+        return finish_device_call();
+    }
+    g_ctx.hw_note = {};
     return hmul_add_impl(H, s_dev, g_dev, g_minor_out_dev, true, w_dev, s_dev);
 }
 

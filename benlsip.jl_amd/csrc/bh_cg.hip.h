@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void step_bounds_kernel(const double* __restri
 __global__ __launch_bounds__(CG_T) void linesearch_kernel(const double* __restrict__ g, double* __restrict__ w,
                                                           const double* __restrict__ wl, const double* __restrict__ wu,
                                                           const int* __restrict__ fixrank, const double* __restrict__ wHw_p,
-                                                          const double* __restrict__ hw, int n, int scale_w, double* __restrict__ out) {
+                                                          double* __restrict__ hw, int n, int scale_w, double* __restrict__ out) {
     __shared__ double scratch[2 * (CG_T / 64)];
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
     OpMinNan opmin;
@@ -563,7 +563,10 @@ __global__ __launch_bounds__(CG_T) void linesearch_kernel(const double* __restri
     const double alpha_opt = (wHw > 0.0) ? __ddiv_rn(-gw[0], wHw) : INF;      // :776
     const double alpha = opmin(alpha_opt, amin[0]);                            // :790
     if (scale_w)
-        for (int i = threadIdx.x; i < n; i += CG_T) w[i] = __dmul_rn(alpha, w[i]);   // :671
+        for (int i = threadIdx.x; i < n; i += CG_T) {
+            w[i] = __dmul_rn(alpha, w[i]);   // :671
+            if (hw != nullptr) hw[i] = __dmul_rn(alpha, hw[i]);      // stays H*w for the scaled w (bh_step_accumulate_dev: g_minor += H*w)
+        }
     if (threadIdx.x == 0) out[0] = alpha;
 }
 

@@ -109,7 +109,13 @@ int32_t bh_comm_unique_id(void* id_out /* BH_UNIQUE_ID_BYTES */);
  * Both return BH_ERR_PRECONDITION while any bh_hess handle is alive: a handle records at creation whether THIS rank applies
  * the replicated C rows (rank 0 does), so the rank must not change under it.  Order: bh_init, bh_comm_init, create handles,
  * ..., destroy handles, bh_comm_destroy.  (nranks == 1 creates no communicator and is always accepted.)
- * BH_RCCL_LIB (environment) names the librccl to load; default: the copy already mapped into the process, else the system one. */
+ * BH_RCCL_LIB (environment) names the librccl to load; default: the copy already mapped into the process, else the system one.
+ * With the peer-buffer transport bh_comm_init ends with a REACHABILITY CHECK: one real exchange of a known vector through every
+ * mapped inbox (timeout BH_PEER_ECHO_TIMEOUT_S, default 5 s).  If it fails on any rank — the mappings opened but a peer's stores
+ * do not land — it fails on EVERY rank (BH_ERR_RCCL, "reachability check failed"), no communicator is left behind, and the caller
+ * may call bh_comm_init again with BH_COMM=rccl.  (BH_PEER_TIMEOUT_S, default 20 s: how long a later exchange waits for a peer
+ * before it poisons its result with NaN and raises the transport's error state.  BH_PEER_ECHO_SKIP_RANK=r: test hook, rank r
+ * stays away from the check.) */
 int32_t bh_comm_init(int32_t rank, int32_t nranks, const void* id /* BH_UNIQUE_ID_BYTES */);
 int32_t bh_comm_destroy(void);
 int32_t bh_comm_info(int32_t* rank, int32_t* nranks);
@@ -293,10 +299,14 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        (needs the caller's factor in bh_proj_set_active)
  *   "pcg_batch"      [0] CG iterations enqueued per launch-ahead batch; 0 = by problem size (1 when an H*p streams >= 100 us)
  *   "fold_init"      [1] box constraints: fold projected_cg's initialisation into the first H*p / step launches
- *   "cg_fused"       [1] box constraints (one rank, or several over the peer-buffer transport): two kernels per CG iteration (the
- *                        H*p launch forms p and takes the exit test, one kernel reduces the slabs — exchanging them between the
- *                        ranks — and updates w, r, v) instead of three (H*p, slab reduction, step kernel);
- *                        2: also linear equalities (reduced form, mA <= 64): four kernels instead of seven; 0: the round-1 shapes
+ *   "cg_fused"       [1] shape of a CG iteration.  1 (default): box constraints in two kernels (the H*p launch forms p and takes the
+ *                        exit test, one kernel reduces the slabs — exchanging them between the ranks of a peer-buffer communicator —
+ *                        and updates w, r, v; over RCCL: two kernels + the collective, the update of the previous iteration
+ *                        living in the prologue of the H*p launch); linear equalities (reduced form, mA <= 64, one rank) in
+ *                        three kernels (H*p, reduce/update, projection with the explicit inverse of the reduced factor).
+ *                        2: linear equalities in four kernels (triangular solves in a launch of their own); box as 1.
+ *                        0: the round-1 shapes (three kernels box, seven with equalities; p'Hp = dot(p, H*p) exactly as the
+ *                        reference forms it, where 1 and 2 form it as sum_i w_i (Jp)_i^2)
  *   "final_sync"     [0] device-pointer entry points (*_dev): 1 = always drain the library stream before returning, as the
  *                        host-pointer entry points do.  0 = return as soon as everything the HOST is owed has arrived; results
  *                        that stay in HBM are ordered on the library stream (later calls see them; bh_synchronize, or sharing
@@ -319,6 +329,11 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "mailbox_flush"  [0] experiment: end the host-pointer entry points with a mailbox seal + poll instead of
  *                        hipStreamSynchronize (measured slower behind a D2H DMA; docs/design_history_r1_r2.md §4)
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
+ *   "step_from_cg"   [1] bh_step_accumulate_dev called right behind the bh_minor_iterate_dev that produced its w (same handle,
+ *                        w_dev = that call's w_out_dev, g_minor_out_dev = that call's g_model_dev, which holds H*s + g as in
+ *                        src/basic_tralcnlss.jl:412,:434-437): g_minor += H*w with the H*w that CG loop accumulated instead of a
+ *                        fresh sweep H*(s + w) + g over J (same value, rounded differently; one H-product less per minor
+ *                        iterate).  0, or any other calling pattern: the explicit product.  Needs "ls_from_cg" = 1.
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = for mA > 64 only: rank-one downdate of the factor itself (O(mA^2)), rebuilt from
  *                        scratch every 8th breakpoint (errors accumulate in between; up to 64 rows the refactoring path is as fast)

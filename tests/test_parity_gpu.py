@@ -1157,6 +1157,65 @@ def final_sync(request, bh):
     bh.set_option("final_sync", 0)
 
 
+@pytest.mark.parametrize("d,n,mA,q", [(700, 130, 0, 0), (900, 257, 3, 1), (4096, 4096, 0, 0)])
+def test_step_accumulate_takes_hw_from_the_cg_loop(bh, d, n, mA, q):
+    """bh_step_accumulate_dev right behind the bh_minor_iterate_dev that produced w (src/basic_tralcnlss.jl:434-437): with
+    option step_from_cg (default) g_minor += H*w uses the H*w the CG loop accumulated — no sweep over J (asserted on the handle's
+    H*p counter) — and must equal the explicit H*(s + w) + g of the ORACLE to 1e-12 of its operands' scale, as the explicit device
+    product (step_from_cg = 0) does; any other calling pattern (another w, a second call) falls back to the explicit product."""
+    import ctypes as ct
+    rng = np.random.default_rng(d + n)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    A = rng.standard_normal((mA, n))
+    xl, xu = -np.ones(n), np.ones(n)
+    x = np.clip(0.4 * rng.standard_normal(n), -0.9, 0.9)
+    fix = np.zeros(n, dtype=bool)
+    fix[rng.choice(n, n // 10, replace=False)] = True
+    x[fix] = 1.0
+    g = rng.standard_normal(n)
+    s0 = 0.01 * rng.standard_normal(n)
+    s0[fix] = 0.0
+    if mA:
+        s0 -= A.T @ np.linalg.solve(A @ A.T, A @ s0)
+        s0[fix] = 0.0
+    Ho = R.AlHessian(J, C, 3.0)
+    gm0 = R.hmul(Ho, s0) + g
+    delta = 0.3 * np.linalg.norm(g)
+    H = bh.AlHessian(J, C, 3.0)
+    cons = bh.MixedConstraints(A, None, fix, l=xl, u=xu)
+    lib = bh._lib.lib()
+    scale = np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(s0))) + np.linalg.norm(g) + 1e-300
+    out = {}
+    for mode in (1, 0):
+        bh.set_option("step_from_cg", mode)
+        dv = {k: bh.DeviceVector(n, v) for k, v in (("x", x), ("s", s0), ("g", g), ("gm", gm0), ("xl", xl), ("xu", xu))}
+        dv["w"] = bh.DeviceVector(n)
+        st, it, nh, al = ct.c_int32(), ct.c_int32(), ct.c_int32(), ct.c_double()
+        bh._lib.check(lib.bh_minor_iterate_dev(H.handle, cons.handle, dv["x"].ptr, dv["s"].ptr, dv["gm"].ptr, dv["xl"].ptr, dv["xu"].ptr, delta, 0.1,
+                                               bh.operators.SQRT_EPS, 1e-10, dv["w"].ptr, ct.byref(st), ct.byref(it), ct.byref(nh), ct.byref(al)), "minor")
+        w = dv["w"].download()
+        n0 = H.stats()["n_hmul"]
+        bh._lib.check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["gm"].ptr), "step")
+        swept = H.stats()["n_hmul"] - n0
+        assert swept == (0 if mode == 1 else 1), (mode, swept)
+        s1, gm1 = dv["s"].download(), dv["gm"].download()
+        assert np.array_equal(s1, s0 + w)
+        ref = R.hmul(Ho, s0 + w) + g
+        out[mode] = gm1
+        err = np.linalg.norm(gm1 - ref) / (scale + np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(w))))
+        note_tol("bh_step_accumulate_dev: g_minor vs the oracle's H*(s+w)+g (1e-12 of the operands' scale)", err, 1e-12, "step_from_cg=%d n=%d" % (mode, n))
+        assert err <= 1e-12, (mode, err)
+        # a second call with the same w is another step (s has changed): it must sweep J again and still be right
+        n0 = H.stats()["n_hmul"]
+        bh._lib.check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["gm"].ptr), "step")
+        assert H.stats()["n_hmul"] - n0 == 1
+        ref2 = R.hmul(Ho, s0 + 2 * w) + g
+        assert np.linalg.norm(dv["gm"].download() - ref2) <= 1e-12 * (scale + 2 * np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(w))))
+    bh.set_option("step_from_cg", 1)
+    H.close(); cons.close()
+
+
 @pytest.mark.parametrize("d,n,mA", [(4096, 512, 0), (1500, 300, 4)])
 def test_inner_step_device_chain_against_oracle(bh, capsys, final_sync, d, n, mA):
     """One whole `inner_step` (src/basic_tralcnlss.jl:394-460: Cauchy search, then minor iterates) against the all-CPU

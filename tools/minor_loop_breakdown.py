@@ -34,7 +34,18 @@ def main():
         "bh_pcg_dev (2 H*p)": lambda: bench.run_steps(bh, H, cons, dv, 0.1, 1),
         "bh_minor_iterate_dev": lambda: lib.bh_minor_iterate_dev(H.handle, Ph, d["x"].ptr, d["s"].ptr, d["g"].ptr, d["xl"].ptr, d["xu"].ptr, delta, 0.1,
                                                                  eps, 1e-10, d["w"].ptr, ct.byref(st), ct.byref(it), ct.byref(nh), ct.byref(al)),
-        "bh_step_accumulate_dev (1 H*p)": lambda: lib.bh_step_accumulate_dev(H.handle, d["s"].ptr, d["w"].ptr, d["g"].ptr, d["gm"].ptr),
+        "bh_step_accumulate_dev (explicit: 1 H*p)": lambda: lib.bh_step_accumulate_dev(H.handle, d["s"].ptr, d["w"].ptr, d["g"].ptr, d["gm"].ptr),
+        # the pair as the inner step calls it (s and g_minor re-uploaded first so that every repetition is the same minor iterate),
+        # and the same without the accumulate: the difference is bh_step_accumulate_dev with H*w taken from the CG loop
+        "upload s, g_minor + bh_minor_iterate_dev": lambda: (
+            d["s"].upload(s0), d["gm"].upload(g),
+            lib.bh_minor_iterate_dev(H.handle, Ph, d["x"].ptr, d["s"].ptr, d["gm"].ptr, d["xl"].ptr, d["xu"].ptr, delta, 0.1,
+                                     eps, 1e-10, d["w"].ptr, ct.byref(st), ct.byref(it), ct.byref(nh), ct.byref(al))),
+        "upload s, g_minor + bh_minor_iterate_dev + bh_step_accumulate_dev (H*w from the CG loop)": lambda: (
+            d["s"].upload(s0), d["gm"].upload(g),
+            lib.bh_minor_iterate_dev(H.handle, Ph, d["x"].ptr, d["s"].ptr, d["gm"].ptr, d["xl"].ptr, d["xu"].ptr, delta, 0.1,
+                                     eps, 1e-10, d["w"].ptr, ct.byref(st), ct.byref(it), ct.byref(nh), ct.byref(al)),
+            lib.bh_step_accumulate_dev(H.handle, d["s"].ptr, d["w"].ptr, d["g"].ptr, d["gm"].ptr)),
         "bh_hmul_dev (1 H*p)": lambda: lib.bh_hmul_dev(H.handle, d["s"].ptr, d["gm"].ptr),
         "bh_proj_update_active_dev": lambda: lib.bh_proj_update_active_dev(Ph, d["x"].ptr, d["s"].ptr, d["xl"].ptr, d["xu"].ptr, delta, eps,
                                                                            ct.byref(na), ct.byref(nf), ct.byref(br), bh._lib.ptr(chunks)),
@@ -53,7 +64,7 @@ def main():
         for _ in range(reps):
             fn()
         lib.bh_synchronize()          # (calls that owe the host nothing return once their work is enqueued)
-        print("%-34s %8.1f us" % (name, 1e6 * (time.perf_counter() - t0) / reps), flush=True)
+        print("%-92s %8.1f us" % (name, 1e6 * (time.perf_counter() - t0) / reps), flush=True)
 
 
 if __name__ == "__main__":
