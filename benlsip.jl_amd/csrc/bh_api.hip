@@ -3176,7 +3176,37 @@ int32_t bh_selftest(void) {
             if (host_out[256 + 64 * w + l] != mn) return fail(BH_ERR_HIP, "wave_min self-test mismatch");
         }
     }
-    return BH_OK;
+    // tri_inv_small_kernel (the explicit inverse behind the three-kernel equality iteration): L Linv = I, Linv' stored
+    // transposed, zeros above the diagonal and beyond m — every block boundary of the recursion (16 / 32 / 64) and odd sizes
+    double *Ld = nullptr, *Wd = nullptr;
+    BH_TRY(dev_alloc(&Ld, 64 * 64 + 64));
+    int32_t rc = dev_alloc(&Wd, 2 * 4096);
+    std::vector<double> L(64 * 64 + 64), W(2 * 4096);
+    for (int m : {1, 2, 7, 15, 16, 17, 31, 32, 33, 48, 63, 64}) {
+        if (rc != BH_OK) break;
+        std::fill(L.begin(), L.end(), std::nan(""));                    // the upper triangle must never be read
+        for (int k = 0; k < m; ++k)
+            for (int i = k; i < m; ++i)
+                L[(size_t)i + (size_t)k * m] = (i == k) ? 1.5 + 0.01 * i : 0.3 * std::sin(1.0 + 0.7 * i + 1.3 * k) / (1.0 + 0.1 * (i - k));
+        for (int i = 0; i < m; ++i) L[(size_t)m * m + i] = 1.0 / L[(size_t)i + (size_t)i * m];
+        if (hipMemcpy(Ld, L.data(), ((size_t)m * m + m) * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(BH_ERR_HIP, "self-test upload"); break; }
+        hipLaunchKernelGGL(tri_inv_small_kernel, dim3(1), dim3(256), 0, g_ctx.stream, (const double*)Ld, m, Wd);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g_ctx.stream) != hipSuccess ||
+            hipMemcpy(W.data(), Wd, W.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(BH_ERR_HIP, "tri_inv self-test launch"); break; }
+        for (int i = 0; i < 64 && rc == BH_OK; ++i)
+            for (int k = 0; k < 64; ++k) {
+                const double x = W[(size_t)k * 64 + i];                 // Linv[i][k]
+                if (W[4096 + (size_t)i * 64 + k] != x) { rc = fail(BH_ERR_HIP, "tri_inv self-test: the transposed copy differs"); break; }
+                if ((i >= m || k >= m || k > i) && x != 0.0) { rc = fail(BH_ERR_HIP, "tri_inv self-test: non-zero outside the triangle"); break; }
+                if (i < m && k <= i) {
+                    long double acc = 0;                                 // (L Linv)[i][k]
+                    for (int l = k; l <= i; ++l) acc += (long double)L[(size_t)i + (size_t)l * m] * (long double)W[(size_t)k * 64 + l];
+                    if (std::fabs((double)acc - (i == k ? 1.0 : 0.0)) > 1e-13) { rc = fail(BH_ERR_HIP, "tri_inv self-test: L Linv != I at m = " + std::to_string(m)); break; }
+                }
+            }
+    }
+    dev_free(Ld); dev_free(Wd);
+    return rc;
 }
 
 }  // extern "C"
