@@ -224,20 +224,25 @@ def self_launch(n_ranks, argv, script=None):
         t.start()
     grace = float(os.environ.get("BH_BENCH_PEER_GRACE_S", "60"))
     rcs, first_fail = [None] * n_ranks, None
-    while any(rc is None for rc in rcs):
-        for r, p in enumerate(procs):
-            if rcs[r] is None:
-                rcs[r] = p.poll()
-                if rcs[r] not in (None, 0) and first_fail is None:
-                    first_fail = time.monotonic()
-                    sys.stderr.write("bench: rank %d exited with code %d\n" % (r, rcs[r]))
-        if first_fail is not None and time.monotonic() - first_fail > grace:
+    try:
+        while any(rc is None for rc in rcs):
             for r, p in enumerate(procs):
                 if rcs[r] is None:
-                    sys.stderr.write("bench: killing rank %d (pid %d), %g s after a peer failed\n" % (r, p.pid, grace))
-                    p.kill()
-            first_fail = float("inf")
-        time.sleep(0.05)
+                    rcs[r] = p.poll()
+                    if rcs[r] not in (None, 0) and first_fail is None:
+                        first_fail = time.monotonic()
+                        sys.stderr.write("bench: rank %d exited with code %d\n" % (r, rcs[r]))
+            if first_fail is not None and time.monotonic() - first_fail > grace:
+                for r, p in enumerate(procs):
+                    if rcs[r] is None:
+                        sys.stderr.write("bench: killing rank %d (pid %d), %g s after a peer failed\n" % (r, p.pid, grace))
+                        p.kill()
+                first_fail = float("inf")
+            time.sleep(0.05)
+    finally:
+        for p in procs:                       # the launcher is going away (interrupt, error): no rank is left behind (exact PIDs)
+            if p.poll() is None:
+                p.kill()
     for t in threads:
         t.join(timeout=5)
     bad = [rc for rc in rcs if rc != 0]

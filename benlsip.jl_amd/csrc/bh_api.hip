@@ -108,8 +108,10 @@ struct Ctx {
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     // bh_step_accumulate_dev right behind the bh_minor_iterate_dev that produced its w: g_minor += H*w with the H*w that CG loop
-    // accumulated (scaled with w by the line search) instead of a fresh sweep H*s + g over J — one H-product less per minor iterate
-    int64_t opt_step_from_cg = 1;
+    // accumulated (scaled with w by the line search) instead of a fresh sweep H*s + g over J — one H-product less per minor iterate.
+    // Opt-in: it relies on the CALLER'S invariant that g_minor_out holds H*s + g for the current s (true in inner_step,
+    // src/basic_tralcnlss.jl:412,:434-437; the library's resident inner-step mirrors switch it on around their loop)
+    int64_t opt_step_from_cg = 0;
     struct { const void* H = nullptr; const double* w = nullptr; const double* gm = nullptr; } hw_note;   // what cg.hw currently is H*w of
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_final_sync = 0;      // *_dev: always drain the stream before returning (1), or only wait for what the host is owed (0)

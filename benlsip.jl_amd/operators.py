@@ -515,23 +515,29 @@ def inner_step(x, g, H, lincons, delta, nb_minor_step, kappa2, kappa3, atol=SQRT
     approx_solved = nrgm <= kappa3 * nrg
     max_minor_step = min(nb_minor_step, n - mA - nfix)                                                       # :425-426
     j, cg_stop, statuses = 1, False, []
-    while j <= max_minor_step and not approx_solved and not cg_stop:                                         # :430
-        status, iters, n_hmul, alpha = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0), ct.c_double(0.0)
-        check(lib.bh_minor_iterate_dev(H.handle, P, dv["x"].ptr, dv["s"].ptr, dv["gm"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta),
-                                       float(kappa2), float(atol), float(atol_f2b), dv["w"].ptr, ct.byref(status), ct.byref(iters),
-                                       ct.byref(n_hmul), ct.byref(alpha)), "bh_minor_iterate_dev")           # :434
-        cg_stop = status.value == int(CGStatus.negative_curvature)
-        check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["gm"].ptr), "bh_step_accumulate_dev")   # :436-437
-        n_at, n_fixed, branch = ct.c_int32(0), ct.c_int32(0), ct.c_int32(0)
-        check(lib.bh_proj_update_active_dev(P, dv["x"].ptr, dv["s"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta), float(atol),
-                                            ct.byref(n_at), ct.byref(n_fixed), ct.byref(branch), ptr(chunks)), "bh_proj_update_active_dev")   # :439-453
-        if branch.value == 0:
-            nrg, nrgm = red_norm(dv["g"]), red_norm(dv["gm"])                                                # :446-447
-            approx_solved = nrgm <= kappa3 * nrg
-        else:
-            approx_solved = True
-        statuses.append((CGStatus(status.value), iters.value, n_fixed.value, nrgm / (kappa3 * nrg) if nrg > 0 else math.inf))
-        j += 1
+    # inside this loop dv["gm"] holds H*s + g for the current s by construction: bh_step_accumulate_dev may add the H*w the CG loop
+    # of the preceding bh_minor_iterate_dev accumulated instead of sweeping J again (option step_from_cg, switched off again below)
+    check(lib.bh_set_option(b"step_from_cg", 1), "bh_set_option")
+    try:
+        while j <= max_minor_step and not approx_solved and not cg_stop:                                         # :430
+            status, iters, n_hmul, alpha = ct.c_int32(-1), ct.c_int32(0), ct.c_int32(0), ct.c_double(0.0)
+            check(lib.bh_minor_iterate_dev(H.handle, P, dv["x"].ptr, dv["s"].ptr, dv["gm"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta),
+                                           float(kappa2), float(atol), float(atol_f2b), dv["w"].ptr, ct.byref(status), ct.byref(iters),
+                                           ct.byref(n_hmul), ct.byref(alpha)), "bh_minor_iterate_dev")           # :434
+            cg_stop = status.value == int(CGStatus.negative_curvature)
+            check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["gm"].ptr), "bh_step_accumulate_dev")   # :436-437
+            n_at, n_fixed, branch = ct.c_int32(0), ct.c_int32(0), ct.c_int32(0)
+            check(lib.bh_proj_update_active_dev(P, dv["x"].ptr, dv["s"].ptr, dv["xlow"].ptr, dv["xupp"].ptr, float(delta), float(atol),
+                                                ct.byref(n_at), ct.byref(n_fixed), ct.byref(branch), ptr(chunks)), "bh_proj_update_active_dev")   # :439-453
+            if branch.value == 0:
+                nrg, nrgm = red_norm(dv["g"]), red_norm(dv["gm"])                                                # :446-447
+                approx_solved = nrgm <= kappa3 * nrg
+            else:
+                approx_solved = True
+            statuses.append((CGStatus(status.value), iters.value, n_fixed.value, nrgm / (kappa3 * nrg) if nrg > 0 else math.inf))
+            j += 1
+    finally:
+        lib.bh_set_option(b"step_from_cg", 0)
     mr = ct.c_double(0.0)
     check(lib.bh_model_reduction_dev(H.handle, dv["g"].ptr, dv["s"].ptr, ct.byref(mr)), "bh_model_reduction_dev")   # :458
     loop_bytes = _xfer(H) - t0

@@ -329,11 +329,13 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "mailbox_flush"  [0] experiment: end the host-pointer entry points with a mailbox seal + poll instead of
  *                        hipStreamSynchronize (measured slower behind a D2H DMA; docs/design_history_r1_r2.md §4)
  *   "ls_from_cg"     [1] bh_minor_iterate: w'Hw of the line search from the H*w the CG loop accumulated (0: explicit vthv)
- *   "step_from_cg"   [1] bh_step_accumulate_dev called right behind the bh_minor_iterate_dev that produced its w (same handle,
+ *   "step_from_cg"   [0] opt-in (the resident inner-step mirrors set it around their loop): bh_step_accumulate_dev called right
+ *                        behind the bh_minor_iterate_dev that produced its w (same handle,
  *                        w_dev = that call's w_out_dev, g_minor_out_dev = that call's g_model_dev, which holds H*s + g as in
  *                        src/basic_tralcnlss.jl:412,:434-437): g_minor += H*w with the H*w that CG loop accumulated instead of a
  *                        fresh sweep H*(s + w) + g over J (same value, rounded differently; one H-product less per minor
- *                        iterate).  0, or any other calling pattern: the explicit product.  Needs "ls_from_cg" = 1.
+ *                        iterate).  It trusts the caller's invariant that g_minor_out_dev holds H*s + g for the CURRENT s.
+ *                        0, or any other calling pattern: the explicit product.  Needs "ls_from_cg" = 1.
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = for mA > 64 only: rank-one downdate of the factor itself (O(mA^2)), rebuilt from
  *                        scratch every 8th breakpoint (errors accumulate in between; up to 64 rows the refactoring path is as fast)

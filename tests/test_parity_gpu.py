@@ -1212,7 +1212,7 @@ def test_step_accumulate_takes_hw_from_the_cg_loop(bh, d, n, mA, q):
         assert H.stats()["n_hmul"] - n0 == 1
         ref2 = R.hmul(Ho, s0 + 2 * w) + g
         assert np.linalg.norm(dv["gm"].download() - ref2) <= 1e-12 * (scale + 2 * np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(w))))
-    bh.set_option("step_from_cg", 1)
+    bh.set_option("step_from_cg", 0)
     H.close(); cons.close()
 
 
