@@ -105,6 +105,9 @@ struct Ctx {
     // with ||g||/||P(-g)|| = 1.7e7 took one more breakpoint than the oracle; after 40, with A_free A_free' close to singular, the
     // projections had left null(A).  Up to 64 rows the refactoring path costs the same, so it is the only one there.
     int64_t opt_chol_downdate = 0;
+    // bh_cauchy_step with box constraints on one rank: 1 = image-space search (J d and J s_c maintained by rank-one column updates:
+    // one J v sweep at the start, then no sweep over J per breakpoint), 0 = one H*d sweep per breakpoint as the reference does
+    int64_t opt_cauchy_image = 1;
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     // bh_step_accumulate_dev right behind the bh_minor_iterate_dev that produced its w: g_minor += H*w with the H*w that CG loop
@@ -363,6 +366,7 @@ int grid_for(int cfg, int64_t nrows) {
 }
 
 constexpr int kEvCap = 512;
+constexpr int kCauchyImgGrid = 512;      // workgroups of cauchy_image_kernel (256 rows each per sweep of the row space)
 
 }  // namespace
 
@@ -381,6 +385,7 @@ struct bh_hess {
     double* zpad = nullptr;        // ld
     double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
     double* tbuf = nullptr;        // d + q   (t = J v between the two passes of a column-panel H*p; NULL for n <= 16384)
+    double* timg = nullptr;        // 2 x (d + q) + 2 x kCauchyImgGrid: t_d = J~ d, t_s = J~ s_c and the partial sums of the image-space Cauchy search (lazy)
     double* partials = nullptr;    // g_cap x ld
     double* sq_partials = nullptr; // 2 x g_cap (second half: per-workgroup minima of the two-kernel CG iteration)
     double* scalar = nullptr;      // 2
@@ -1349,6 +1354,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "step_from_cg")) { g_ctx.opt_step_from_cg = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cauchy_image")) { g_ctx.opt_cauchy_image = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "image_pool")) {
         if (value < 0 || value > 8) return fail(BH_ERR_INVALID_ARG, "image_pool must be 0..8");
@@ -1801,7 +1807,7 @@ int32_t bh_hess_destroy(bh_hess* H) {
     } else {
         dev_free(H->Jd);
     }
-    dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf);
+    dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf); dev_free(H->timg);
     dev_free(H->partials); dev_free(H->sq_partials); dev_free(H->scalar);
     for (auto e : H->ev) if (e) (void)hipEventDestroy(e);
     delete H;
@@ -2944,12 +2950,38 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     if (c.tag == 0) c.tag = 1;
     a.mirror = c.d_mirror; a.tag = c.tag;
 
+    // Box constraints, one rank: the image-space search (bh_cauchy.hip.h) — t_d = J~ d once by the J v kernel, then per breakpoint
+    // a rank-one update of t_d, t_s over the rows (one column of J) + the single-workgroup advance kernel; no sweep over J.
+    const bool image = (mA == 0) && !comm_active() && g_ctx.opt_cauchy_image != 0;
+    const int64_t img_rows = H->d + H->q_eff;
+    const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 255) / 256));
+    if (image) {
+        BH_TRY(hess_ready(H));
+        if (!H->timg) BH_TRY(dev_alloc(&H->timg, 2 * std::max<int64_t>(H->d + H->q, 1) + 2 * kCauchyImgGrid));
+        a.img_part = H->timg + 2 * std::max<int64_t>(H->d + H->q, 1);
+        a.img_G = img_grid;
+    }
+
     P->active_set = false;             // device mask is authoritative until adopt_mask below
     hipLaunchKernelGGL(cauchy_init_kernel, dim3(1), dim3(CG_T), 0, s, a);
     if (mA > 0) BH_TRY(launch_reduced_factor(P, true, nullptr));
     const int max_pass = (int)(n + 1);
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
+        if (image) {
+            const int64_t rows_cap = std::max<int64_t>(H->d + H->q, 1);
+            if (index == 0) {
+                BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));                  // t_d = J~ d_0 (:609 in the row space)
+                H->stats.n_jv += 1;
+            }
+            CauchyImgArgs ia{};
+            ia.st = c.d_state; ia.J = H->Jd; ia.ld = H->ld; ia.nrows = img_rows; ia.d_rows = H->d; ia.mu = H->mu;
+            ia.td = H->timg; ia.ts = H->timg + rows_cap; ia.part = H->timg + 2 * rows_cap; ia.first = index == 0 ? 1 : 0;
+            hipLaunchKernelGGL(cauchy_image_kernel, dim3(img_grid), dim3(256), 0, s, ia);
+            hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CG_T), 0, s, a);
+            BH_HIP(hipGetLastError());
+            return BH_OK;
+        }
         if (index > 0 && mA > 0) {
             // chol_downdate = 1 only has a case where refactoring is expensive (mA > 64: blocked factorisation, 0.21 ms at mA = 256);
             // up to 64 rows the register-panel Cholesky (18.5 us) costs what the rank-one downdate costs (20 us), so the factor is
@@ -2979,7 +3011,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         return BH_OK;
     };
     MirrorWord mw{};
-    const int batch = launch_batch_size(H);
+    const int batch = image ? 8 : launch_batch_size(H);          // image-space passes take ~10 us: keep a deeper queue ahead of the GPU
     auto launch_batch = [&](int nb) -> int32_t {
         nb = std::min(nb, max_pass - launched);
         for (int i = 0; i < nb; ++i) BH_TRY(launch_pass(launched + i));
@@ -3001,7 +3033,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     BH_TRY(fetch_vec(s_out, c.w, n, dev));
     int info_host = 0;
     BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host));     // drains the stream; canonical fixrank / fixidx, P->nfix
-    H->stats.n_hmul += mw.n_hmul;
+    if (!image) H->stats.n_hmul += mw.n_hmul;                  // (image-space search: passes, not sweeps over J)
     if (!mw.done) return fail(BH_ERR_HIP, "internal: Cauchy loop did not terminate");
     if (n_breakpoints) *n_breakpoints = mw.iter;
     if (n_hmul_out) *n_hmul_out = mw.n_hmul;

@@ -25,7 +25,46 @@ struct CauchyArgs {
     double delta, atol;
     int box;                // mA == 0: the projection is a mask, so it is maintained in place (d[ind] = 0 when ind becomes fixed)
     unsigned long long* mirror; unsigned tag;
+    // image-space search (box constraints): s'Hd and d'Hd arrive as per-workgroup partial sums over the rows of J (cauchy_image_kernel)
+    const double* img_part; int img_G;
 };
+
+// Image-space form of the box-constrained search.  With box constraints a breakpoint only zeroes one component of d, so in the
+// row space of J~ = [J; sqrt-weighted C] the two vectors  t_d = J~ d  and  t_s = J~ s_c  follow by rank-one updates
+//     t_s += theta t_d ,   t_d -= d_ind J~[:, ind]        (one COLUMN of J: d + q strided loads, 4 MiB of traffic at config 3)
+// and the search's scalars are  d'Hd = sum_i w_i t_d,i^2  and  s_c'Hd = sum_i w_i t_s,i t_d,i  (:610-611, :634-635) — the same
+// numbers as dot(d, H*d) and dot(s_c, H*d), rounded differently, without the sweep over J that H*d costs per breakpoint (:633):
+// one J v sweep for t_d at the start, then ~10 us per breakpoint instead of ~317 us.
+struct CauchyImgArgs {
+    const CgState* st;
+    const double* J; int64_t ld; int64_t nrows, d_rows; double mu;
+    double* td; double* ts;
+    double* part;           // [2][gridDim.x]: partial sums of w t_s t_d and of w t_d^2
+    int first;              // pass 0: t_d = J d has just been formed by the J v kernel, t_s = 0: no update, only the sums
+};
+
+__global__ __launch_bounds__(256) void cauchy_image_kernel(CauchyImgArgs a) {
+    const CgState* st = a.st;
+    if (st->done) return;
+    __shared__ double scratch[2 * 4];
+    const int ind = st->status;                 // the variable fixed at the previous breakpoint, its step and its old d component
+    const double theta = st->gamma, dind = st->beta;
+    double acc[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256) {
+        double td = a.td[i], ts = 0.0;
+        if (!a.first) {
+            ts = __dadd_rn(a.ts[i], __dmul_rn(theta, td));                       // s_c += theta d          (:628)
+            td = __dsub_rn(td, __dmul_rn(dind, a.J[i * a.ld + ind]));            // d[ind] = 0              (:632, box)
+            a.td[i] = td;
+        }
+        a.ts[i] = ts;
+        const double w = (i < a.d_rows) ? 1.0 : a.mu;
+        acc[0] = fma(w * ts, td, acc[0]);
+        acc[1] = fma(w * td, td, acc[1]);
+    }
+    block_reduce<256, 2>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+}
 
 __device__ __forceinline__ void publish_cauchy(const CauchyArgs& a, const CgState* st) {
     if (a.mirror == nullptr) return;
@@ -80,13 +119,16 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
     // the first batch's d and s are kept for the update below.
     constexpr int E = 4;
     double d0[E], s0[E];
+    const bool img = a.img_part != nullptr;      // s'Hd and d'Hd come from the row-space partial sums: Hd is not read
+    double img_sums[2] = {0.0, 0.0};
+    if (img) { img_sums[0] = wave_fixed_sum(a.img_part, a.img_G); img_sums[1] = wave_fixed_sum(a.img_part + a.img_G, a.img_G); }
     for (int base = 0; base < a.n; base += E * CG_T) {
         double dv[E], hv[E], sv[E], gv[E], lv[E], uv[E];
         int fv[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) {
             const int i = min(base + tid + k * CG_T, a.n - 1);
-            dv[k] = a.d[i]; hv[k] = a.Hd[i]; sv[k] = a.s[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixrank[i];
+            dv[k] = a.d[i]; hv[k] = img ? 0.0 : a.Hd[i]; sv[k] = a.s[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixrank[i];
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) {
@@ -107,6 +149,7 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
     }
     block_reduce<CG_T, 2>(sums, scratch, OpSum(), 0.0);
     block_reduce<CG_T, 1>(gd, scratch, OpSum(), 0.0);
+    if (img) { sums[0] = img_sums[0]; sums[1] = img_sums[1]; }
     // arg-min with the smallest index among equal thetas
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -148,12 +191,13 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
             if (i >= a.n) continue;
             a.s[i] = __dadd_rn(s0[k], __dmul_rn(step, d0[k]));
             // box constraints: projection!(lincons, -g, d) after add_active!(ind) only zeroes d[ind] (:632) — done by the
-            // thread that owns the element, after it has used the old value
-            if (advance && a.box && i == ind) a.d[i] = 0.0;
+            // thread that owns the element, after it has used the old value (kept in st->beta for the image-space update)
+            if (advance && a.box && i == ind) { st->beta = d0[k]; a.d[i] = 0.0; }
         }
         for (int i = E * CG_T + tid; i < a.n; i += CG_T) {
-            a.s[i] = __dadd_rn(a.s[i], __dmul_rn(step, a.d[i]));
-            if (advance && a.box && i == ind) a.d[i] = 0.0;
+            const double di = a.d[i];
+            a.s[i] = __dadd_rn(a.s[i], __dmul_rn(step, di));
+            if (advance && a.box && i == ind) { st->beta = di; a.d[i] = 0.0; }
         }
     }
     if (tid == 0) {

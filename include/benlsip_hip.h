@@ -339,6 +339,9 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = for mA > 64 only: rank-one downdate of the factor itself (O(mA^2)), rebuilt from
  *                        scratch every 8th breakpoint (errors accumulate in between; up to 64 rows the refactoring path is as fast)
+ *   "cauchy_image"   [1] bh_cauchy_step with box constraints on one rank: search in the row space of J (J d and J s_c maintained by
+ *                        one-column updates; d'Hd = ||J d||^2_W, s'Hd = (J s).(J d)_W: the same numbers as dot(d, H*d), dot(s, H*d),
+ *                        rounded differently): one J v sweep at the start instead of one H*d sweep per breakpoint.  0: as the reference
  *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)
  *   "gram_mfma"      [1] A_free A_free' on fp64 MFMA when mA > 96 (2: always, 0: never)
  *   "rs_variant"     [0] A/B geometries of the row-streaming kernel for 2048 < n <= 4096 (tools/kernel_ab.py)

@@ -914,6 +914,58 @@ def test_cauchy_step_parity(bh, chol_downdate, d, n, mA, nact, delta_scale, seed
     assert np.linalg.norm(bh.projection(cons, r) - R.projection(cons_o, r)) <= 1e-10 * np.linalg.norm(r)
 
 
+@pytest.mark.parametrize("d,n,q,nact,delta_scale,seed", [(90, 33, 2, 3, 1.0, 11), (700, 257, 1, 20, 3.0, 12), (3000, 1024, 0, 100, 10.0, 13), (257, 4100, 3, 50, 1.0, 14),
+                                                         (5, 3, 1, 0, 5.0, 15)])
+def test_cauchy_step_in_the_row_space_of_j(bh, capsys, d, n, q, nact, delta_scale, seed):
+    """Box constraints: the image-space search (option cauchy_image, default) maintains J d and J s_c by one-column updates and
+    forms d'Hd = ||J d||^2_W, s'Hd = (J s).(J d)_W from them — no sweep over J per breakpoint.  Against the oracle (which sweeps, as
+    the reference does, src/basic_tralcnlss.jl:609,:633): same breakpoints, same final active set, same step to 1e-9 — also with
+    nonlinear-constraint rows (q > 0, weight mu) — and the same against the device's own sweeping form (cauchy_image = 0); the
+    handle's H*p counter shows that no sweep ran."""
+    rng = np.random.default_rng(seed)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    xlow, xupp = -np.ones(n), np.ones(n)
+    x = np.clip(0.5 * rng.standard_normal(n), -0.95, 0.95)
+    act = rng.choice(n, nact, replace=False)
+    x[act] = np.where(rng.random(nact) < 0.5, -1.0, 1.0)
+    g = rng.standard_normal(n)
+    delta = delta_scale * 0.1 * np.linalg.norm(g)
+    Z = np.zeros((0, n))
+    L0 = R.chol_lower(Z @ Z.T)
+    Ho = R.AlHessian(J, C, 2.5)
+    cons_o = R.make_mixed_constraints(Z, L0, l=xlow, u=xupp)
+    calls = [0]
+
+    class Ops(R.NumpyOps):
+        def hmul(self, H, v):
+            calls[0] += 1
+            return R.hmul(H, v)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, Ops())
+    H = bh.AlHessian(J, C, 2.5)
+    out = {}
+    for mode in (1, 0):
+        bh.set_option("cauchy_image", mode)
+        try:
+            cons = bh.MixedConstraints(Z, None, l=xlow, u=xupp)
+            n0 = H.stats()["n_hmul"]
+            s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+            swept = H.stats()["n_hmul"] - n0
+        finally:
+            bh.set_option("cauchy_image", 1)
+        assert np.array_equal(cons.fixvars, cons_o.fixvars), (mode, np.flatnonzero(cons.fixvars), np.flatnonzero(cons_o.fixvars))
+        assert info["n_hmul"] == calls[0]                                   # passes = the oracle's H*d products
+        assert swept == (0 if mode == 1 else calls[0]), (mode, swept, calls[0])
+        rel = relnorm(s, s_ref)
+        note_tol("cauchy_step (box): step vs oracle, 1e-9", rel, 1e-9, "cauchy_image=%d d=%d n=%d q=%d, %d breakpoints" % (mode, d, n, q, info["n_breakpoints"]))
+        assert rel <= 1e-9, (mode, rel)
+        assert np.all(x + s <= xupp + 1e-12) and np.all(x + s >= xlow - 1e-12) and np.max(np.abs(s)) <= delta * (1 + 1e-12)
+        out[mode] = s
+        cons.close()
+    assert relnorm(out[1], out[0]) <= 1e-9
+    H.close()
+
+
 def test_cauchy_step_on_the_pinned_multimodal_operands(bh, capsys, chol_downdate):
     """the worst Cauchy discrepancies of the device shadow solve, with their operands committed
     (tests/golden/cauchy_events.json).  tests/test_oracle_cpu.py shows that on these operands the ORACLE ALONE lands on several
