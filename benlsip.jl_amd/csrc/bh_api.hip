@@ -2952,14 +2952,18 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
 
     // Box constraints, one rank: the image-space search (bh_cauchy.hip.h) — t_d = J~ d once by the J v kernel, then per breakpoint
     // a rank-one update of t_d, t_s over the rows (one column of J) + the single-workgroup advance kernel; no sweep over J.
-    const bool image = (mA == 0) && !comm_active() && g_ctx.opt_cauchy_image != 0;
+    // (several ranks: every rank keeps t_d, t_s for ITS rows; the two sums are all-reduced before the replicated advance kernel)
+    const bool image = (mA == 0) && g_ctx.opt_cauchy_image != 0;
     const int64_t img_rows = H->d + H->q_eff;
     const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 255) / 256));
+    const int64_t img_cap = 2 * (std::max<int64_t>(H->d + H->q, 1) + 1) / 2 * 2;          // rows, rounded up to even (16-byte aligned tails)
+    double* img_scal = nullptr;
     if (image) {
         BH_TRY(hess_ready(H));
-        if (!H->timg) BH_TRY(dev_alloc(&H->timg, 2 * std::max<int64_t>(H->d + H->q, 1) + 2 * kCauchyImgGrid));
-        a.img_part = H->timg + 2 * std::max<int64_t>(H->d + H->q, 1);
-        a.img_G = img_grid;
+        if (!H->timg) BH_TRY(dev_alloc(&H->timg, 2 * img_cap + 2 * kCauchyImgGrid + 16));
+        img_scal = H->timg + 2 * img_cap + 2 * kCauchyImgGrid;
+        a.img_part = comm_active() ? img_scal : H->timg + 2 * img_cap;
+        a.img_G = comm_active() ? 1 : img_grid;
     }
 
     P->active_set = false;             // device mask is authoritative until adopt_mask below
@@ -2969,7 +2973,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
         if (image) {
-            const int64_t rows_cap = std::max<int64_t>(H->d + H->q, 1);
+            const int64_t rows_cap = img_cap;
             if (index == 0) {
                 BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));                  // t_d = J~ d_0 (:609 in the row space)
                 H->stats.n_jv += 1;
@@ -2978,6 +2982,10 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
             ia.st = c.d_state; ia.J = H->Jd; ia.ld = H->ld; ia.nrows = img_rows; ia.d_rows = H->d; ia.mu = H->mu;
             ia.td = H->timg; ia.ts = H->timg + rows_cap; ia.part = H->timg + 2 * rows_cap; ia.first = index == 0 ? 1 : 0;
             hipLaunchKernelGGL(cauchy_image_kernel, dim3(img_grid), dim3(256), 0, s, ia);
+            if (comm_active()) {
+                hipLaunchKernelGGL(cauchy_image_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)ia.part, img_grid, img_scal, (const CgState*)c.d_state);
+                BH_TRY(allreduce_inplace(img_scal, 2, H, c.d_state));
+            }
             hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CG_T), 0, s, a);
             BH_HIP(hipGetLastError());
             return BH_OK;
@@ -3011,7 +3019,8 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         return BH_OK;
     };
     MirrorWord mw{};
-    const int batch = image ? 8 : launch_batch_size(H);          // image-space passes take ~10 us: keep a deeper queue ahead of the GPU
+    // image-space passes take ~17 us: keep a deeper queue ahead of the GPU (over RCCL every over-launched pass costs a collective)
+    const int batch = !image ? launch_batch_size(H) : (comm_active() && !use_peer_path()) ? 4 : 8;
     auto launch_batch = [&](int nb) -> int32_t {
         nb = std::min(nb, max_pass - launched);
         for (int i = 0; i < nb; ++i) BH_TRY(launch_pass(launched + i));

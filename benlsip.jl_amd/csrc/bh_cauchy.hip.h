@@ -43,6 +43,13 @@ struct CauchyImgArgs {
     int first;              // pass 0: t_d = J d has just been formed by the J v kernel, t_s = 0: no update, only the sums
 };
 
+// Several ranks: this rank's two sums (its rows of J) in scal[0..1], ready for the all-reduce that precedes the advance kernel.
+__global__ __launch_bounds__(64) void cauchy_image_sum_kernel(const double* __restrict__ part, int G, double* __restrict__ scal, const CgState* st) {
+    if (st->done) return;
+    const double a = wave_fixed_sum(part, G), b = wave_fixed_sum(part + G, G);
+    if (threadIdx.x == 0) { scal[0] = a; scal[1] = b; }
+}
+
 __global__ __launch_bounds__(256) void cauchy_image_kernel(CauchyImgArgs a) {
     const CgState* st = a.st;
     if (st->done) return;

@@ -88,6 +88,13 @@ def main():
     s_c, info = bh.cauchy_step(P["x"], P["g_cauchy"], H, cau, 0.5 * np.linalg.norm(P["g_cauchy"]), full_output=True)
     out["cauchy_s"], out["cauchy_fix"], out["cauchy_nh"] = s_c, np.asarray(cau.fixvars, dtype=bool), info["n_hmul"]
 
+    # the same with box constraints only: the image-space search (every rank keeps J d, J s_c for its rows; two scalars all-reduced
+    # per breakpoint)
+    cau_box = bh.MixedConstraints(Z, None, None, l=P["xlow"], u=P["xupp"])
+    g_big = 1000.0 * P["g_cauchy"]            # a steep gradient: the breakpoints come 1000 x closer, the search passes many of them
+    s_b, info_b = bh.cauchy_step(P["x"], g_big, H, cau_box, 0.5 * np.linalg.norm(g_big), full_output=True)
+    out["cauchy_box_s"], out["cauchy_box_fix"], out["cauchy_box_passes"] = s_b, np.asarray(cau_box.fixvars, dtype=bool), info_b["n_hmul"]
+
     st = H.stats()
     out["n_allreduce"] = st["n_allreduce"]
     np.savez(os.path.join(workdir, "rank%d.npz" % rank), **out)

@@ -145,6 +145,13 @@ def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     s_ref = R.cauchy_step(P["x"], P["g_cauchy"], Ho, L0, cau, 0.5 * np.linalg.norm(P["g_cauchy"]), R.NumpyOps())
     assert np.array_equal(z["cauchy_fix"], cau.fixvars)
     assert np.linalg.norm(z["cauchy_s"] - s_ref) <= 1e-9 * np.linalg.norm(s_ref)
+    Zc = np.zeros((0, n))
+    cau_b = R.make_mixed_constraints(Zc, R.chol_lower(Zc @ Zc.T), l=P["xlow"], u=P["xupp"])
+    g_big = 1000.0 * P["g_cauchy"]
+    sb_ref = R.cauchy_step(P["x"], g_big, Ho, R.chol_lower(Zc @ Zc.T), cau_b, 0.5 * np.linalg.norm(g_big), R.NumpyOps())
+    print("[multirank %s x%d] box Cauchy search in the row space: %d passes, %d active bounds" % (comm, world, int(z["cauchy_box_passes"]), int(cau_b.fixvars.sum())))
+    assert np.array_equal(z["cauchy_box_fix"], cau_b.fixvars) and int(z["cauchy_box_passes"]) >= 10
+    assert np.linalg.norm(z["cauchy_box_s"] - sb_ref) <= 1e-9 * np.linalg.norm(sb_ref)
     assert int(z["n_allreduce"]) >= int(z["box_tight_nh"]) + int(z["cauchy_nh"])
 
 
