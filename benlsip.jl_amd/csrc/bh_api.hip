@@ -108,6 +108,7 @@ struct Ctx {
     // bh_cauchy_step with box constraints on one rank: 1 = image-space search (J d and J s_c maintained by rank-one column updates:
     // one J v sweep at the start, then no sweep over J per breakpoint), 0 = one H*d sweep per breakpoint as the reference does
     int64_t opt_cauchy_image = 1;
+    int64_t opt_cauchy_image_max_ma = 16;   // ... and with up to this many linear equalities (their row-space form costs 1 + mA J v sweeps up front)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     // bh_step_accumulate_dev right behind the bh_minor_iterate_dev that produced its w: g_minor += H*w with the H*w that CG loop
@@ -386,6 +387,8 @@ struct bh_hess {
     double* upad = nullptr;        // d + q   (J'u input staging / J v output staging)
     double* tbuf = nullptr;        // d + q   (t = J v between the two passes of a column-panel H*p; NULL for n <= 16384)
     double* timg = nullptr;        // 2 x (d + q) + 2 x kCauchyImgGrid: t_d = J~ d, t_s = J~ s_c and the partial sums of the image-space Cauchy search (lazy)
+    double* timg_gen = nullptr;    // (1 + mA) x (d + q): a = J~ D g and B = J~ D A' of its linear-equality form (lazy, grown on demand)
+    int64_t timg_gen_doubles = 0;
     double* partials = nullptr;    // g_cap x ld
     double* sq_partials = nullptr; // 2 x g_cap (second half: per-workgroup minima of the two-kernel CG iteration)
     double* scalar = nullptr;      // 2
@@ -1355,6 +1358,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image")) { g_ctx.opt_cauchy_image = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cauchy_image_max_ma")) { g_ctx.opt_cauchy_image_max_ma = std::min<int64_t>(std::max<int64_t>(0, value), 64); return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "image_pool")) {
         if (value < 0 || value > 8) return fail(BH_ERR_INVALID_ARG, "image_pool must be 0..8");
@@ -1807,7 +1811,7 @@ int32_t bh_hess_destroy(bh_hess* H) {
     } else {
         dev_free(H->Jd);
     }
-    dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf); dev_free(H->timg);
+    dev_free(H->vpad); dev_free(H->zpad); dev_free(H->upad); dev_free(H->tbuf); dev_free(H->timg); dev_free(H->timg_gen);
     dev_free(H->partials); dev_free(H->sq_partials); dev_free(H->scalar);
     for (auto e : H->ev) if (e) (void)hipEventDestroy(e);
     delete H;
@@ -2953,7 +2957,8 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     // Box constraints, one rank: the image-space search (bh_cauchy.hip.h) — t_d = J~ d once by the J v kernel, then per breakpoint
     // a rank-one update of t_d, t_s over the rows (one column of J) + the single-workgroup advance kernel; no sweep over J.
     // (several ranks: every rank keeps t_d, t_s for ITS rows; the two sums are all-reduced before the replicated advance kernel)
-    const bool image = (mA == 0) && g_ctx.opt_cauchy_image != 0;
+    const bool image = g_ctx.opt_cauchy_image != 0 && (mA == 0 || mA <= g_ctx.opt_cauchy_image_max_ma);
+    const bool image_gen = image && mA > 0;
     const int64_t img_rows = H->d + H->q_eff;
     const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 255) / 256));
     const int64_t img_cap = 2 * (std::max<int64_t>(H->d + H->q, 1) + 1) / 2 * 2;          // rows, rounded up to even (16-byte aligned tails)
@@ -2964,6 +2969,12 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         img_scal = H->timg + 2 * img_cap + 2 * kCauchyImgGrid;
         a.img_part = comm_active() ? img_scal : H->timg + 2 * img_cap;
         a.img_G = comm_active() ? 1 : img_grid;
+        if (image_gen && H->timg_gen_doubles < (int64_t)(1 + mA) * img_cap) {
+            dev_free(H->timg_gen);
+            H->timg_gen = nullptr; H->timg_gen_doubles = 0;
+            BH_TRY(dev_alloc(&H->timg_gen, (int64_t)(1 + mA) * img_cap));
+            H->timg_gen_doubles = (int64_t)(1 + mA) * img_cap;
+        }
     }
 
     P->active_set = false;             // device mask is authoritative until adopt_mask below
@@ -2974,14 +2985,38 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     auto launch_pass = [&](int index) -> int32_t {
         if (image) {
             const int64_t rows_cap = img_cap;
-            if (index == 0) {
-                BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));                  // t_d = J~ d_0 (:609 in the row space)
-                H->stats.n_jv += 1;
-            }
             CauchyImgArgs ia{};
             ia.st = c.d_state; ia.J = H->Jd; ia.ld = H->ld; ia.nrows = img_rows; ia.d_rows = H->d; ia.mu = H->mu;
             ia.td = H->timg; ia.ts = H->timg + rows_cap; ia.part = H->timg + 2 * rows_cap; ia.first = index == 0 ? 1 : 0;
-            hipLaunchKernelGGL(cauchy_image_kernel, dim3(img_grid), dim3(256), 0, s, ia);
+            if (image_gen) {
+                // factor of the current active set and y = (A_free A_free')^{-1} A_free(-g) (left in P->tw), as in the sweeping form
+                if (index > 0) {
+                    hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
+                                       (const CgState*)c.d_state);
+                    BH_TRY(launch_chol(P, (const CgState*)c.d_state));
+                }
+                BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));               // d = P(-g) for the advance kernel's g.d and s update
+                if (index == 0) {
+                    // a = J~ D g and the mA columns of B = J~ D A': 1 + mA J v sweeps over masked vectors (fixed components zero)
+                    const int mgrid = std::max(1, std::min((int)((n + 255) / 256), 1024));
+                    for (int j = -1; j < mA; ++j) {
+                        const double* src = (j < 0) ? a.g : (const double*)(P->Ad + (int64_t)j * P->ldA);
+                        hipLaunchKernelGGL(proj_mask_kernel, dim3(mgrid), dim3(256), 0, s, src, H->vpad, (const int*)P->fixrank, (int)n, (const CgState*)nullptr);
+                        BH_TRY(launch_jv(H, H->vpad, H->timg_gen + (int64_t)(j + 1) * rows_cap, true, nullptr));
+                        H->stats.n_jv += 1;
+                    }
+                }
+                CauchyImgGenArgs ga{};
+                ga.b = ia; ga.a = H->timg_gen; ga.B = H->timg_gen + rows_cap; ga.rows_cap = rows_cap; ga.mA = mA;
+                ga.A = P->Ad; ga.ldA = P->ldA; ga.tw = P->tw; ga.g = a.g;
+                hipLaunchKernelGGL(cauchy_image_gen_kernel, dim3(img_grid), dim3(256), 0, s, ga);
+            } else {
+                if (index == 0) {
+                    BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));              // t_d = J~ d_0 (:609 in the row space)
+                    H->stats.n_jv += 1;
+                }
+                hipLaunchKernelGGL(cauchy_image_kernel, dim3(img_grid), dim3(256), 0, s, ia);
+            }
             if (comm_active()) {
                 hipLaunchKernelGGL(cauchy_image_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)ia.part, img_grid, img_scal, (const CgState*)c.d_state);
                 BH_TRY(allreduce_inplace(img_scal, 2, H, c.d_state));

@@ -43,6 +43,60 @@ struct CauchyImgArgs {
     int first;              // pass 0: t_d = J d has just been formed by the J v kernel, t_s = 0: no update, only the sums
 };
 
+// The same with linear equalities (reduced projection form, small mA).  d = P(-g) = -D g - D A'y changes in every free component
+// per breakpoint (D = mask of the free variables, y = (A_free A_free')^{-1} A_free(-g), left in ProjArgs::tw by the projection
+// kernels), but in the row space it is  t_d = J~ d = -a - B y  with  a = J~ D g  (rows)  and  B = J~ D A'  (rows x mA, stored
+// column by column), and fixing variable `ind` is a one-column update of both:  a -= g_ind J~[:, ind],  B -= J~[:, ind] A[:, ind]'.
+// a and B cost 1 + mA J v sweeps at the start; afterwards a breakpoint costs rows x (mA + 3) doubles of traffic instead of a sweep.
+struct CauchyImgGenArgs {
+    CauchyImgArgs b;
+    double* a;              // rows
+    double* B;              // mA x rows_cap (column j at B + j * rows_cap)
+    int64_t rows_cap;
+    int mA;
+    const double* A; int64_t ldA;     // row-major mA x ldA image of lineq
+    const double* tw;       // y (mA), written by the projection of this pass
+    const double* g;
+};
+
+__global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs ga) {
+    const CauchyImgArgs& a = ga.b;
+    const CgState* st = a.st;
+    if (st->done) return;
+    __shared__ double scratch[2 * 4];
+    __shared__ double s_acol[64], s_y[64];
+    const int ind = st->status;
+    const double theta = st->gamma;
+    const bool upd = !a.first && ind >= 0;
+    if ((int)threadIdx.x < ga.mA) {
+        s_acol[threadIdx.x] = upd ? ga.A[(int64_t)threadIdx.x * ga.ldA + ind] : 0.0;
+        s_y[threadIdx.x] = ga.tw[threadIdx.x];
+    }
+    const double g_ind = upd ? ga.g[ind] : 0.0;
+    __syncthreads();
+    double acc[2] = {0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256) {
+        double ts = 0.0;
+        if (!a.first) ts = __dadd_rn(a.ts[i], __dmul_rn(theta, a.td[i]));        // s_c += theta d  with the PREVIOUS d   (:628)
+        const double col = upd ? a.J[i * a.ld + ind] : 0.0;
+        double ai = ga.a[i];
+        if (upd) { ai = __dsub_rn(ai, __dmul_rn(g_ind, col)); ga.a[i] = ai; }
+        double td = -ai;
+        for (int j = 0; j < ga.mA; ++j) {
+            double bij = ga.B[(int64_t)j * ga.rows_cap + i];
+            if (upd) { bij = __dsub_rn(bij, __dmul_rn(col, s_acol[j])); ga.B[(int64_t)j * ga.rows_cap + i] = bij; }
+            td = fma(-bij, s_y[j], td);
+        }
+        a.td[i] = td;
+        a.ts[i] = ts;
+        const double w = (i < a.d_rows) ? 1.0 : a.mu;
+        acc[0] = fma(w * ts, td, acc[0]);
+        acc[1] = fma(w * td, td, acc[1]);
+    }
+    block_reduce<256, 2>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+}
+
 // Several ranks: this rank's two sums (its rows of J) in scal[0..1], ready for the all-reduce that precedes the advance kernel.
 __global__ __launch_bounds__(64) void cauchy_image_sum_kernel(const double* __restrict__ part, int G, double* __restrict__ scal, const CgState* st) {
     if (st->done) return;

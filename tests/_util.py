@@ -132,6 +132,36 @@ def cauchy_outcomes(P, e, ops, samples, seed):
     return out
 
 
+def check_cauchy_against_cpu_family(P, e, s, key_dev, samples=32, seed=0):
+    """What can be demanded of a Cauchy step where the outcome is decided by rounding (P: anything with .A, .x_l, .x_u; e: the
+    operands x, g, delta, mu, J, C, fix0): feasibility, and model value / active-set size inside the range that the two CPU
+    restatements (augmented form = the oracle, reduced form) span under 1-ulp perturbations of g; where CPU outcomes share the
+    device's final set, the step as close to them as they are to each other (or 1e-6).  Returns a summary dict."""
+    cpu = cauchy_outcomes(P, e, R.NumpyOps(), samples, seed=seed) + cauchy_outcomes(P, e, ReducedFormOps(), samples, seed=seed)
+    phis = np.array([model_value(e, sc) for sc, _ in cpu])
+    sizes = [len(k) for _, k in cpu]
+    as_rel = lambda v: float(np.linalg.norm(P.A @ v) / (max(np.linalg.norm(P.A), 1e-300) * max(np.linalg.norm(v), 1e-300))) if P.A.shape[0] else 0.0
+    phi_dev = model_value(e, s)
+    same_set = [sc for sc, k in cpu if k == key_dev]
+    info = dict(phi_dev=phi_dev, phi_min=float(phis.min()), phi_max=float(phis.max()), size_dev=len(key_dev), size_min=min(sizes), size_max=max(sizes),
+                n_sets=len({k for _, k in cpu}), as_rel_dev=as_rel(s), as_rel_cpu=max(as_rel(sc) for sc, _ in cpu), same_set=len(same_set),
+                nearest=min(relnorm(s, sc) for sc, _ in cpu))
+    assert np.max(np.abs(s)) <= e["delta"] * (1 + 1e-12), info
+    assert np.all(e["x"] + s <= P.x_u + 1e-12) and np.all(e["x"] + s >= P.x_l - 1e-12), info
+    assert info["as_rel_dev"] <= 10.0 * info["as_rel_cpu"] + 1e-12, info
+    note_tol("Cauchy step where rounding decides: model value inside the CPU outcomes' range (+-5 %)",
+             max(phi_dev - phis.max(), phis.min() - phi_dev, 0.0) + 0.0, 0.05 * max(abs(phis.min()), abs(phis.max())), "delta %.1e" % e["delta"])
+    assert phis.min() - 0.05 * abs(phis.min()) <= phi_dev <= phis.max() + 0.05 * abs(phis.max()), info
+    assert min(sizes) - 2 <= len(key_dev) <= max(sizes) + 2, info
+    if same_set:
+        spread = max(relnorm(sa, sb) for sa in same_set[:8] for sb in same_set)
+        info["same_set_dist"] = min(relnorm(s, sc) for sc in same_set)
+        assert info["same_set_dist"] <= max(1e-6, spread), (info, spread)
+    if info["n_sets"] == 1:
+        assert key_dev == cpu[0][1], info
+    return info
+
+
 def model_value(e, s):
     """phi(s) = g.s + 1/2 s'Hs — what the Cauchy search minimises along the projected-gradient path (:610-611)."""
     return float(e["g"] @ s + 0.5 * R.vthv(R.AlHessian(e["J"], e["C"], e["mu"]), s))

@@ -267,5 +267,6 @@ class ShadowOps:
                                     fix_dev=int(lincons.fixvars.sum()), fix_cpu=int(shadow.fixvars.sum()),
                                     g_over_reduced_g=float(np.linalg.norm(g) / max(np.linalg.norm(red), 1e-300)),
                                     operands=dict(x=x.copy(), g=g.copy(), delta=delta, fix0=fix0.copy(), J=H[1].J.copy(), C=H[1].C.copy(), mu=H[1].mu,
-                                                  s_dev=s.copy(), s_cpu=s_o.copy())))
+                                                  s_dev=s.copy(), s_cpu=s_o.copy(), fix_dev_set=lincons.fixvars.copy(),
+                                                  A=lincons.lineq.copy(), x_l=lincons.xlow.copy(), x_u=lincons.xupp.copy())))
         return s

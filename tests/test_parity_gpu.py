@@ -966,7 +966,8 @@ def test_cauchy_step_in_the_row_space_of_j(bh, capsys, d, n, q, nact, delta_scal
     H.close()
 
 
-def test_cauchy_step_on_the_pinned_multimodal_operands(bh, capsys, chol_downdate):
+@pytest.mark.parametrize("image", [1, 0], ids=["row_space_form", "sweep_per_breakpoint"])
+def test_cauchy_step_on_the_pinned_multimodal_operands(bh, capsys, image):
     """the worst Cauchy discrepancies of the device shadow solve, with their operands committed
     (tests/golden/cauchy_events.json).  tests/test_oracle_cpu.py shows that on these operands the ORACLE ALONE lands on several
     final active sets under 1-ulp perturbations of g, and a reduced-form CPU restatement on yet others — the outcome is not
@@ -977,38 +978,28 @@ def test_cauchy_step_on_the_pinned_multimodal_operands(bh, capsys, chol_downdate
         margin), and so does the size of its final active set (+-2);
       * where CPU outcomes have exactly the device's final active set, the device's step is as close to them as they are to each
         other (or 1e-6); where every CPU outcome has the SAME active set (the two unimodal events), so has the device.
-    (Both per-breakpoint factor updates; since round 3 chol_downdate = 1 applies to mA > 64 only — this test found its one-wave
-    kernel for mA <= 64 walking to the corner of the trust region on event 511: 46 active bounds, |As|/|A||s| = 4e-6.)"""
-    from _util import ReducedFormOps, cauchy_outcomes, load_cauchy_events, model_value
+    Both forms of the device search: in the row space of J (default for mA <= 16) and with one H*d sweep per breakpoint.
+    (History: this test found the one-wave factor-downdate kernel for mA <= 64 walking to the corner of the trust region on event
+    511 — 46 active bounds, |As|/|A||s| = 4e-6; that kernel is gone, chol_downdate = 1 now applies to mA > 64 only.)"""
+    from _util import check_cauchy_against_cpu_family, load_cauchy_events
     P, events = load_cauchy_events()
+    chol_downdate = 0
     for e in events:
         H = bh.AlHessian(e["J"], e["C"], e["mu"])
         cons = bh.MixedConstraints(P.A, None, None, l=P.x_l, u=P.x_u)
-        s, info = bh.cauchy_step(e["x"], e["g"], H, cons, e["delta"], full_output=True)
+        bh.set_option("cauchy_image", image)
+        try:
+            s, info = bh.cauchy_step(e["x"], e["g"], H, cons, e["delta"], full_output=True)
+        finally:
+            bh.set_option("cauchy_image", 1)
         key_dev = tuple(np.flatnonzero(cons.fixvars))
-        cpu = cauchy_outcomes(P, e, R.NumpyOps(), 32, seed=e["minor"]) + cauchy_outcomes(P, e, ReducedFormOps(), 32, seed=e["minor"])
-        phis = np.array([model_value(e, sc) for sc, _ in cpu])
-        sizes = [len(k) for _, k in cpu]
-        as_rel = lambda v: float(np.linalg.norm(P.A @ v) / (np.linalg.norm(P.A) * max(np.linalg.norm(v), 1e-300)))
-        phi_dev = model_value(e, s)
-        same_set = [sc for sc, k in cpu if k == key_dev]
-        nearest = min(relnorm(s, sc) for sc, _ in cpu)
+        info = check_cauchy_against_cpu_family(P, e, s, key_dev, samples=32, seed=e["minor"])
         with capsys.disabled():
-            print("[pinned Cauchy event, minor iterate %d, chol_downdate=%d] device: %d active bounds, phi %.4e, |As|/|A||s| %.1e; CPU outcomes: sizes %d..%d "
+            print("[pinned Cauchy event, minor iterate %d, cauchy_image=%d] device: %d active bounds, phi %.4e, |As|/|A||s| %.1e; CPU outcomes: sizes %d..%d "
                   "(%d distinct sets), phi %.4e .. %.4e, |As|/|A||s| <= %.1e; same set on the CPU: %s; nearest CPU outcome at %.1e"
-                  % (e["minor"], chol_downdate, len(key_dev), phi_dev, as_rel(s), min(sizes), max(sizes), len({k for _, k in cpu}), phis.min(), phis.max(),
-                     max(as_rel(sc) for sc, _ in cpu), "no" if not same_set else "yes, steps %.1e apart" % min(relnorm(s, sc) for sc in same_set), nearest))
-        assert np.max(np.abs(s)) <= e["delta"] * (1 + 1e-12)
-        assert np.all(e["x"] + s <= P.x_u + 1e-12) and np.all(e["x"] + s >= P.x_l - 1e-12)
-        assert as_rel(s) <= 10.0 * max(as_rel(sc) for sc, _ in cpu) + 1e-12
-        assert phis.min() - 0.05 * abs(phis.min()) <= phi_dev <= phis.max() + 0.05 * abs(phis.max()), (phi_dev, phis.min(), phis.max())
-        assert min(sizes) - 2 <= len(key_dev) <= max(sizes) + 2
-        if same_set:
-            # same breakpoint sequence: as close to the CPU outcomes with that set as they are to each other (or 1e-6)
-            spread = max(relnorm(sa, sb) for sa in same_set[:8] for sb in same_set)
-            assert min(relnorm(s, sc) for sc in same_set) <= max(1e-6, spread), (min(relnorm(s, sc) for sc in same_set), spread)
-        if len({k for _, k in cpu}) == 1:
-            assert key_dev == cpu[0][1]
+                  % (e["minor"], image, info["size_dev"], info["phi_dev"], info["as_rel_dev"], info["size_min"], info["size_max"], info["n_sets"],
+                     info["phi_min"], info["phi_max"], info["as_rel_cpu"],
+                     "no" if not info["same_set"] else "yes, steps %.1e apart" % info["same_set_dist"], info["nearest"]))
         H.close(); cons.close()
 
 
@@ -1689,15 +1680,23 @@ def check_shadow_events(sh):
       * a projection must agree to 1e-10 of its operand's norm (ShadowOps records anything above);
       * the result of a Cauchy search / minor iterate may deviate by more than 1e-6 only as far as the ORACLE's own result
         moves when its right-hand side is perturbed in the last bit (both are cancelling computations near a critical point:
-        the direction P(-g) carries ||g||/||P(-g)|| = 1e5 ... 1e9 of amplification there, whoever computes it); a different
-        active set out of the Cauchy search is accepted only where that sensitivity says the oracle itself is undecided."""
+        the direction P(-g) carries ||g||/||P(-g)|| = 1e5 ... 1e9 of amplification there, whoever computes it);
+      * a Cauchy search that ends on another active set than the oracle's must pass the property check of the pinned-operands test
+        against the family of CPU outcomes on ITS operands (tests/_util.py::check_cauchy_against_cpu_family)."""
     for e in sh.events:
         ev = {k: v for k, v in e.items() if k != "operands"}
         if e["op"] == "minor_iterate" and (e["status_dev"] != e["status_cpu"] or e["iters_dev"] != e["iters_cpu"]):
             assert e["ties"] is not None and e["ties"]["tie_flags"] != 0, "status / iteration count differ on identical operands without a logged tie: %r" % (ev,)
         elif e["op"] == "projection":
             raise AssertionError("projection deviates on identical operands: %r" % (ev,))
+        elif e["op"] == "cauchy_step" and e["fix_dev"] != e["fix_cpu"]:
+            # another final active set than the oracle's on identical operands: accepted only if the outcome is within what the CPU
+            # restatements themselves produce on these operands under 1-ulp perturbations of g (feasibility, model value, set size,
+            # agreement with outcomes that share its set) — the rule of test_cauchy_step_on_the_pinned_multimodal_operands
+            from types import SimpleNamespace
+            from _util import check_cauchy_against_cpu_family
+            op = e["operands"]
+            check_cauchy_against_cpu_family(SimpleNamespace(A=op["A"], x_l=op["x_l"], x_u=op["x_u"]), op, op["s_dev"],
+                                            tuple(np.flatnonzero(op["fix_dev_set"])), samples=16, seed=e["minor"])
         else:
             assert e["rel"] <= max(1e-6, 20.0 * e["oracle_sensitivity"]), ev
-            if e["op"] == "cauchy_step" and e["fix_dev"] != e["fix_cpu"]:
-                assert e["oracle_sensitivity"] >= 1e-3, ev
