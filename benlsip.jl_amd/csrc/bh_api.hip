@@ -117,6 +117,9 @@ struct Ctx {
     // src/basic_tralcnlss.jl:412,:434-437; the library's resident inner-step mirrors switch it on around their loop)
     int64_t opt_step_from_cg = 0;
     struct { const void* H = nullptr; const double* w = nullptr; const double* gm = nullptr; } hw_note;   // what cg.hw currently is H*w of
+    // the last (H, s, g, g_minor) for which the library itself wrote g_minor = H*s + g (bh_hmul_add_dev, bh_step_accumulate_dev):
+    // with step_from_cg on, bh_model_reduction_dev on the same H, s, g takes s'Hs = s.(g_minor - g) instead of sweeping J
+    struct { const void* H = nullptr; const double* s = nullptr; const double* g = nullptr; const double* gm = nullptr; } gm_note;
     int64_t opt_fold_init = 1;       // box CG: fold the initialisation into the first H*p / step launches
     int64_t opt_final_sync = 0;      // *_dev: always drain the stream before returning (1), or only wait for what the host is owed (0)
     // the end-of-call wait of the host-pointer entry points: hipStreamSynchronize (0) or a mailbox seal + poll (1: A/B'd, SLOWER —
@@ -1797,6 +1800,7 @@ int32_t bh_hess_set_mu(bh_hess* H, double mu) {
 
 int32_t bh_hess_destroy(bh_hess* H) {
     if (H && g_ctx.hw_note.H == H) g_ctx.hw_note = {};
+    if (H && g_ctx.gm_note.H == H) g_ctx.gm_note = {};
     if (!H) return BH_OK;
     if (H->up) {                              // an upload still in flight: let it finish before its buffers go
         AsyncUpload* u = H->up;
@@ -2745,6 +2749,7 @@ static int32_t hmul_add_impl(bh_hess* H, const double* s_vec, const double* g, d
     }
     BH_TRY(dev ? finish_device_call() : sync_flush());
     H->stats.n_hmul += 1;
+    if (dev) g_ctx.gm_note = {H, s_vec, g, out_n}; else g_ctx.gm_note = {};
     return BH_OK;
 }
 int32_t bh_hmul_add(bh_hess* H, const double* s_vec, const double* g, double* out_n) { return hmul_add_impl(H, s_vec, g, out_n, false); }
@@ -2766,6 +2771,7 @@ int32_t bh_step_accumulate_dev(bh_hess* H, double* s_dev, const double* w_dev, c
         hipLaunchKernelGGL(vec_add_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const double*)g_minor_out_dev, (const double*)g_ctx.cg.hw,
                            g_minor_out_dev, (int)n);
         BH_HIP(hipGetLastError());
+        g_ctx.gm_note = {H, s_dev, g_dev, g_minor_out_dev};
         return finish_device_call();
     }
     g_ctx.hw_note = {};
@@ -2862,6 +2868,16 @@ int32_t bh_model_reduction_dev(bh_hess* H, const double* g_dev, const double* s_
     if (!H || !g_dev || !s_dev || !out) return fail(BH_ERR_INVALID_ARG, "NULL argument");
     BH_TRY(ensure_cg_workspace(H->ld, 0));
     CgWorkspace& c = g_ctx.cg;
+    if (g_ctx.opt_step_from_cg && g_ctx.gm_note.H == H && g_ctx.gm_note.s == s_dev && g_ctx.gm_note.g == g_dev && g_ctx.gm_note.gm != nullptr) {
+        // the library wrote g_minor = H*s + g for exactly these vectors (and, by the caller's opt-in, nobody has touched them since):
+        // s'Hs = s.(g_minor - g), g.s — no sweep over J (the rounding of the difference is that of g.s itself: eps |g||s|)
+        hipLaunchKernelGGL(model_from_gminor_kernel, dim3(1), dim3(CG_T), 0, g_ctx.stream, g_dev, s_dev, g_ctx.gm_note.gm, (int)H->n, c.scalars + 2);
+        BH_HIP(hipGetLastError());
+        BH_TRY(mbox_ensure());
+        BH_TRY(mbox_seal_and_wait(2 * sizeof(double), c.scalars + 2, c.scalars + 3, mbox_dev<double>(kMbScal)));
+        *out = mbox_host<double>(kMbScal)[1] + 0.5 * mbox_host<double>(kMbScal)[0];
+        return BH_OK;
+    }
     const double* sp = H->vpad;
     BH_TRY(device_operand(&sp, H->vpad, s_dev, H->n, H->ld));
     BH_TRY(launch_jv(H, sp, nullptr, true, H->scalar));

@@ -175,4 +175,19 @@ __global__ __launch_bounds__(CG_T) void vec_dot_kernel(const double* __restrict_
     if (threadIdx.x == 0) out[0] = acc[0];
 }
 
+// model_reduction = g.s + s'Hs / 2 (src/basic_tralcnlss.jl:458) from a g_minor that holds H*s + g:  out[0] = s.(g_minor - g) = s'Hs,
+// out[1] = g.s — two dot products instead of a J v sweep.
+__global__ __launch_bounds__(CG_T) void model_from_gminor_kernel(const double* __restrict__ g, const double* __restrict__ sv,
+                                                                 const double* __restrict__ gm, int n, double* __restrict__ out) {
+    __shared__ double scratch[2 * (CG_T / 64)];
+    double acc[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += CG_T) {
+        const double si = sv[i], gi = g[i];
+        acc[0] = fma(si, __dsub_rn(gm[i], gi), acc[0]);
+        acc[1] = fma(gi, si, acc[1]);
+    }
+    block_reduce<CG_T, 2>(acc, scratch, OpSum(), 0.0);
+    if (threadIdx.x == 0) { out[0] = acc[0]; out[1] = acc[1]; }
+}
+
 }  // namespace bh

@@ -515,8 +515,9 @@ def inner_step(x, g, H, lincons, delta, nb_minor_step, kappa2, kappa3, atol=SQRT
     approx_solved = nrgm <= kappa3 * nrg
     max_minor_step = min(nb_minor_step, n - mA - nfix)                                                       # :425-426
     j, cg_stop, statuses = 1, False, []
-    # inside this loop dv["gm"] holds H*s + g for the current s by construction: bh_step_accumulate_dev may add the H*w the CG loop
-    # of the preceding bh_minor_iterate_dev accumulated instead of sweeping J again (option step_from_cg, switched off again below)
+    # from here on dv["gm"] holds H*s + g for the current s by construction: bh_step_accumulate_dev may add the H*w the CG loop of
+    # the preceding bh_minor_iterate_dev accumulated instead of sweeping J again, and bh_model_reduction_dev may take s'Hs from
+    # g_minor (option step_from_cg, switched off again below)
     check(lib.bh_set_option(b"step_from_cg", 1), "bh_set_option")
     try:
         while j <= max_minor_step and not approx_solved and not cg_stop:                                         # :430
@@ -536,10 +537,11 @@ def inner_step(x, g, H, lincons, delta, nb_minor_step, kappa2, kappa3, atol=SQRT
                 approx_solved = True
             statuses.append((CGStatus(status.value), iters.value, n_fixed.value, nrgm / (kappa3 * nrg) if nrg > 0 else math.inf))
             j += 1
+        # :458 — still under the invariant: s'Hs = s.(g_minor - g) from the resident g_minor instead of a J v sweep
+        mr = ct.c_double(0.0)
+        check(lib.bh_model_reduction_dev(H.handle, dv["g"].ptr, dv["s"].ptr, ct.byref(mr)), "bh_model_reduction_dev")
     finally:
         lib.bh_set_option(b"step_from_cg", 0)
-    mr = ct.c_double(0.0)
-    check(lib.bh_model_reduction_dev(H.handle, dv["g"].ptr, dv["s"].ptr, ct.byref(mr)), "bh_model_reduction_dev")   # :458
     loop_bytes = _xfer(H) - t0
     s = dv["s"].download()
     lincons._fixvars = np.unpackbits(chunks.view(np.uint8), bitorder="little")[:n].astype(bool)

@@ -335,6 +335,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        src/basic_tralcnlss.jl:412,:434-437): g_minor += H*w with the H*w that CG loop accumulated instead of a
  *                        fresh sweep H*(s + w) + g over J (same value, rounded differently; one H-product less per minor
  *                        iterate).  It trusts the caller's invariant that g_minor_out_dev holds H*s + g for the CURRENT s.
+ *                        Under the same option bh_model_reduction_dev(H, g, s) takes s'Hs = s.(g_minor - g) from the g_minor the
+ *                        library last wrote for exactly these H, s, g (bh_hmul_add_dev / bh_step_accumulate_dev) instead of a J v sweep.
  *                        0, or any other calling pattern: the explicit product.  Needs "ls_from_cg" = 1.
  *   "chol_downdate"  [0] bh_cauchy_step, per breakpoint: 0 = downdate the Gram matrix and refactor (as accurate as the reference's
  *                        from-scratch rebuild), 1 = for mA > 64 only: rank-one downdate of the factor itself (O(mA^2)), rebuilt from

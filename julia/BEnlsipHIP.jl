@@ -265,10 +265,10 @@ function BEnlsip.inner_step(x::Vector{Float64}, g::Vector{Float64}, H::BEnlsip.A
         end
         j += 1
     end
-    check(ccall((:bh_set_option, libbh), Int32, (Cstring, Int64), "step_from_cg", 0), "bh_set_option(step_from_cg)")
-    mr = Ref{Float64}(0.0)
+    mr = Ref{Float64}(0.0)                    # still under the invariant: s'Hs = s.(g_minor - g) from the resident g_minor, no J*v sweep
     check(ccall((:bh_model_reduction_dev, libbh), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), hH, dv[:g].ptr, dv[:s].ptr, mr),
           "bh_model_reduction_dev")                                                                                                   # :458
+    check(ccall((:bh_set_option, libbh), Int32, (Cstring, Int64), "step_from_cg", 0), "bh_set_option(step_from_cg)")
     s = Vector{Float64}(undef, n)
     download!(s, dv[:s])
     BEnlsip.update_chol!(lincons, chol_aat)       # one refresh of the host factor (a no-op under skip_host_factor!)

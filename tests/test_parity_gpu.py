@@ -1249,6 +1249,14 @@ def test_step_accumulate_takes_hw_from_the_cg_loop(bh, d, n, mA, q):
         err = np.linalg.norm(gm1 - ref) / (scale + np.linalg.norm(np.abs(J).T @ (np.abs(J) @ np.abs(w))))
         note_tol("bh_step_accumulate_dev: g_minor vs the oracle's H*(s+w)+g (1e-12 of the operands' scale)", err, 1e-12, "step_from_cg=%d n=%d" % (mode, n))
         assert err <= 1e-12, (mode, err)
+        # bh_model_reduction_dev on the same H, s, g (:458): under the option s'Hs comes from the g_minor just written, no J v sweep
+        mr, j0 = ct.c_double(), H.stats()["n_jv"]
+        bh._lib.check(lib.bh_model_reduction_dev(H.handle, dv["g"].ptr, dv["s"].ptr, ct.byref(mr)), "model reduction")
+        assert H.stats()["n_jv"] - j0 == (0 if mode == 1 else 1)
+        mr_ref = float(g @ s1) + 0.5 * R.vthv(Ho, s1)
+        note_tol("bh_model_reduction_dev vs oracle (1e-10 of |g||s| + s'Hs)", abs(mr.value - mr_ref), 1e-10 * (np.linalg.norm(g) * np.linalg.norm(s1) + R.vthv(Ho, s1)),
+                 "step_from_cg=%d n=%d" % (mode, n))
+        assert abs(mr.value - mr_ref) <= 1e-10 * (np.linalg.norm(g) * np.linalg.norm(s1) + R.vthv(Ho, s1)), (mode, mr.value, mr_ref)
         # a second call with the same w is another step (s has changed): it must sweep J again and still be right
         n0 = H.stats()["n_hmul"]
         bh._lib.check(lib.bh_step_accumulate_dev(H.handle, dv["s"].ptr, dv["w"].ptr, dv["g"].ptr, dv["gm"].ptr), "step")
