@@ -426,6 +426,7 @@ struct bh_proj {
     double* tpart = nullptr;       // (ldA/32 + 1) x mA: per-workgroup partials of A_free r (three- / four-kernel CG iteration)
     double* W = nullptr;           // 2 x 64 x 64: [Linv | Linv'] of the reduced factor, mA <= 64 (tri_inv_small_kernel)
     bool linv_valid = false;       // W belongs to the current Lr
+    int last_cauchy_passes = 0;    // passes of the previous bh_cauchy_step on this handle (decides whether 1 + mA set-up sweeps pay off)
     bool reduced = false;          // form used by bh_project / bh_pcg for the current active set
     bool M_valid = false;          // M = A_free A_free' for the CURRENT active set (false after factor-only downdates)
     std::vector<uint64_t> last_chunks;   // fixvars of the last successful bh_proj_set_active (reduced form: skip identical pushes)
@@ -2973,11 +2974,14 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     // Box constraints, one rank: the image-space search (bh_cauchy.hip.h) — t_d = J~ d once by the J v kernel, then per breakpoint
     // a rank-one update of t_d, t_s over the rows (one column of J) + the single-workgroup advance kernel; no sweep over J.
     // (several ranks: every rank keeps t_d, t_s for ITS rows; the two sums are all-reduced before the replicated advance kernel)
-    const bool image = g_ctx.opt_cauchy_image != 0 && (mA == 0 || mA <= g_ctx.opt_cauchy_image_max_ma);
+    // With linear equalities the form costs 1 + mA J v sweeps up front: always used up to cauchy_image_max_ma rows; up to 64 rows when
+    // the previous search on this handle took more than 4 (1 + mA) passes (consecutive searches of a solve behave alike).
+    const bool image = g_ctx.opt_cauchy_image != 0 &&
+                       (mA == 0 || mA <= g_ctx.opt_cauchy_image_max_ma || (mA <= 64 && P->last_cauchy_passes > 4 * (1 + mA)));
     const bool image_gen = image && mA > 0;
     const int64_t img_rows = H->d + H->q_eff;
     const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 255) / 256));
-    const int64_t img_cap = 2 * (std::max<int64_t>(H->d + H->q, 1) + 1) / 2 * 2;          // rows, rounded up to even (16-byte aligned tails)
+    const int64_t img_cap = (std::max<int64_t>(H->d + H->q, 1) + 1) / 2 * 2;              // rows, rounded up to even (16-byte aligned tails)
     double* img_scal = nullptr;
     if (image) {
         BH_TRY(hess_ready(H));
@@ -3094,6 +3098,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     int info_host = 0;
     BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host));     // drains the stream; canonical fixrank / fixidx, P->nfix
     if (!image) H->stats.n_hmul += mw.n_hmul;                  // (image-space search: passes, not sweeps over J)
+    P->last_cauchy_passes = mw.n_hmul;
     if (!mw.done) return fail(BH_ERR_HIP, "internal: Cauchy loop did not terminate");
     if (n_breakpoints) *n_breakpoints = mw.iter;
     if (n_hmul_out) *n_hmul_out = mw.n_hmul;

@@ -345,7 +345,9 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        one-column updates; d'Hd = ||J d||^2_W, s'Hd = (J s).(J d)_W: the same numbers as dot(d, H*d), dot(s, H*d),
  *                        rounded differently): one J v sweep at the start instead of one H*d sweep per breakpoint.  0: as the reference
  *   "cauchy_image_max_ma" [16] ... and with up to this many linear equalities (0..64): there the row-space form keeps a = J D g and
- *                        B = J D A' (rows x mA) next to J d, J s_c — 1 + mA J v sweeps up front, one column of J per breakpoint afterwards
+ *                        B = J D A' (rows x mA) next to J d, J s_c — 1 + mA J v sweeps up front, one column of J per breakpoint
+ *                        afterwards; between this value and 64 rows the form is used when the previous search on the same bh_proj
+ *                        took more than 4 (1 + mA) passes
  *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)
  *   "gram_mfma"      [1] A_free A_free' on fp64 MFMA when mA > 96 (2: always, 0: never)
  *   "rs_variant"     [0] A/B geometries of the row-streaming kernel for 2048 < n <= 4096 (tools/kernel_ab.py)

@@ -966,6 +966,38 @@ def test_cauchy_step_in_the_row_space_of_j(bh, capsys, d, n, q, nact, delta_scal
     H.close()
 
 
+def test_cauchy_step_row_space_form_chosen_from_history(bh, capsys):
+    """Between 17 and 64 linear equalities the row-space form of the Cauchy search (1 + mA J v sweeps up front) is used when the
+    previous search on the same handle took more than 4 (1 + mA) passes: first call sweeping (one H*d per breakpoint), second call
+    in the row space (no H*d) — both against the oracle: same active set, step to 1e-9."""
+    rng = np.random.default_rng(77)
+    d, n, mA = 900, 400, 20
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    xlow, xupp = -np.ones(n), np.ones(n)
+    x = np.clip(0.5 * rng.standard_normal(n), -0.95, 0.95)
+    g = 1000.0 * rng.standard_normal(n)                       # steep: hundreds of breakpoints
+    delta = 0.5 * np.linalg.norm(g)
+    Ho = R.AlHessian(J, np.zeros((0, n)), 10.0)
+    cons_o = R.make_mixed_constraints(A, L0, l=xlow, u=xupp)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, R.NumpyOps())
+    H = bh.AlHessian(J, None, 10.0)
+    cons = bh.MixedConstraints(A, None, l=xlow, u=xupp)
+    swept = []
+    for call in range(2):
+        n0 = H.stats()["n_hmul"]
+        s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+        swept.append(H.stats()["n_hmul"] - n0)
+        assert np.array_equal(cons.fixvars, cons_o.fixvars), call
+        assert relnorm(s, s_ref) <= 1e-9, (call, relnorm(s, s_ref))
+    with capsys.disabled():
+        print("[Cauchy search, mA = 20] %d passes; H*d sweeps: first call %d, second call %d (row-space form chosen from history)"
+              % (info["n_hmul"], swept[0], swept[1]))
+    assert info["n_hmul"] > 4 * (1 + mA) and swept[0] == info["n_hmul"] and swept[1] == 0
+    H.close(); cons.close()
+
+
 @pytest.mark.parametrize("image", [1, 0], ids=["row_space_form", "sweep_per_breakpoint"])
 def test_cauchy_step_on_the_pinned_multimodal_operands(bh, capsys, image):
     """the worst Cauchy discrepancies of the device shadow solve, with their operands committed
