@@ -108,7 +108,8 @@ struct Ctx {
     // bh_cauchy_step with box constraints on one rank: 1 = image-space search (J d and J s_c maintained by rank-one column updates:
     // one J v sweep at the start, then no sweep over J per breakpoint), 0 = one H*d sweep per breakpoint as the reference does
     int64_t opt_cauchy_image = 1;
-    int64_t opt_cauchy_image_max_ma = 16;   // ... and with up to this many linear equalities (their row-space form costs 1 + mA J v sweeps up front)
+    int64_t opt_cauchy_image_max_ma = 64;   // ... and with up to this many linear equalities (0..64)
+    int64_t opt_cauchy_gemm = 1;            // B = J D A' of that form in one sweep on the matrix cores (0: mA J v sweeps over masked rows of A)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
     // bh_step_accumulate_dev right behind the bh_minor_iterate_dev that produced its w: g_minor += H*w with the H*w that CG loop
@@ -1362,6 +1363,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image")) { g_ctx.opt_cauchy_image = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cauchy_gemm")) { g_ctx.opt_cauchy_gemm = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image_max_ma")) { g_ctx.opt_cauchy_image_max_ma = std::min<int64_t>(std::max<int64_t>(0, value), 64); return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "image_pool")) {
@@ -3017,13 +3019,20 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                 }
                 BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));               // d = P(-g) for the advance kernel's g.d and s update
                 if (index == 0) {
-                    // a = J~ D g and the mA columns of B = J~ D A': 1 + mA J v sweeps over masked vectors (fixed components zero)
+                    // a = J~ D g: one J v sweep over the masked g.  B = J~ D A' (rows x mA): ONE sweep on the matrix cores
+                    // (image_b_mfma_kernel) when the images share their leading dimension, else mA J v sweeps over masked rows of A
                     const int mgrid = std::max(1, std::min((int)((n + 255) / 256), 1024));
-                    for (int j = -1; j < mA; ++j) {
+                    const bool gemm = g_ctx.opt_cauchy_gemm != 0 && P->ldA == H->ld;
+                    for (int j = -1; j < (gemm ? 0 : mA); ++j) {
                         const double* src = (j < 0) ? a.g : (const double*)(P->Ad + (int64_t)j * P->ldA);
                         hipLaunchKernelGGL(proj_mask_kernel, dim3(mgrid), dim3(256), 0, s, src, H->vpad, (const int*)P->fixrank, (int)n, (const CgState*)nullptr);
                         BH_TRY(launch_jv(H, H->vpad, H->timg_gen + (int64_t)(j + 1) * rows_cap, true, nullptr));
                         H->stats.n_jv += 1;
+                    }
+                    if (gemm) {
+                        hipLaunchKernelGGL(image_b_mfma_kernel, dim3((unsigned)((img_rows + 63) / 64)), dim3(256), 0, s, (const double*)H->Jd, H->ld,
+                                           img_rows, (const double*)P->Ad, P->ldA, mA, (const int*)P->fixrank, H->timg_gen + rows_cap, rows_cap);
+                        BH_HIP(hipGetLastError());
                     }
                 }
                 CauchyImgGenArgs ga{};

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include "bh_reduce.hip.h"
 #include "bh_cg.hip.h"
+#include "bh_proj.hip.h"   // dvec4
 
 namespace bh {
 
@@ -95,6 +96,63 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs 
     }
     block_reduce<256, 2>(acc, scratch, OpSum(), 0.0);
     if (threadIdx.x == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+}
+
+// B = J~ D A'  (rows x mA, column j at B + j * rows_cap) on the matrix cores: the one place on this path where a tile of J meets a
+// dense GEMM (M = rows of J, N = mA <= 64, K = n) — 1 + mA J v sweeps became one sweep.  v_mfma_f64_16x16x4_f64; a wave owns a
+// strip of 16 rows of J and all four 16-column tiles of the output; the K index is permuted as in gram_free_mfma_kernel (lane group
+// l >> 4 owns 4 consecutive columns of every 16-column super-step: one 32-byte load per lane and operand, 128 contiguous bytes per
+// matrix row); two accumulation chains per tile; fixed variables are masked out of the A operand (D).  Fixed order: bit-reproducible.
+__global__ __launch_bounds__(256) void image_b_mfma_kernel(const double* __restrict__ J, int64_t ld, int64_t nrows, const double* __restrict__ A,
+                                                           int64_t ldA, int mA, const int* __restrict__ fixrank, double* __restrict__ B,
+                                                           int64_t rows_cap) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t strip = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    if (strip >= nrows) return;
+    const int ri = lane & 15, kq = lane >> 4;
+    const bool vrow = strip + ri < nrows;
+    const double* pj = J + (vrow ? strip + ri : 0) * ld + 4 * kq;
+    const double* pa[4];
+    bool va[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        va[t] = 16 * t + ri < mA;
+        pa[t] = A + (int64_t)(va[t] ? 16 * t + ri : 0) * ldA + 4 * kq;
+    }
+    dvec4 acc0[4], acc1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { acc0[t] = dvec4{0.0, 0.0, 0.0, 0.0}; acc1[t] = dvec4{0.0, 0.0, 0.0, 0.0}; }
+    const int nsuper = (int)(ld >> 4);               // ld (= ldA) is a multiple of 16; the padding columns of both images are zero
+#pragma unroll 2
+    for (int sidx = 0; sidx < nsuper; ++sidx) {
+        const int64_t c = (int64_t)sidx * 16;
+        double2 j01 = make_double2(0.0, 0.0), j23 = j01;
+        if (vrow) { j01 = *reinterpret_cast<const double2*>(pj + c); j23 = *reinterpret_cast<const double2*>(pj + c + 2); }
+        int4 f = make_int4(-1, -1, -1, -1);
+        if (fixrank != nullptr) f = *reinterpret_cast<const int4*>(fixrank + c + 4 * kq);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double2 a01 = make_double2(0.0, 0.0), a23 = a01;
+            if (va[t]) { a01 = *reinterpret_cast<const double2*>(pa[t] + c); a23 = *reinterpret_cast<const double2*>(pa[t] + c + 2); }
+            if (f.x >= 0) a01.x = 0.0;
+            if (f.y >= 0) a01.y = 0.0;
+            if (f.z >= 0) a23.x = 0.0;
+            if (f.w >= 0) a23.y = 0.0;
+            acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j01.x, a01.x, acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j01.y, a01.y, acc1[t], 0, 0, 0);
+            acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j23.x, a23.x, acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j23.y, a23.y, acc1[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = 16 * t + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = strip + (lane >> 4) + 4 * r;
+            if (col < mA && row < nrows) B[(int64_t)col * rows_cap + row] = acc0[t][r] + acc1[t][r];
+        }
+    }
 }
 
 // Several ranks: this rank's two sums (its rows of J) in scal[0..1], ready for the all-reduce that precedes the advance kernel.

@@ -344,10 +344,12 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "cauchy_image"   [1] bh_cauchy_step with box constraints on one rank: search in the row space of J (J d and J s_c maintained by
  *                        one-column updates; d'Hd = ||J d||^2_W, s'Hd = (J s).(J d)_W: the same numbers as dot(d, H*d), dot(s, H*d),
  *                        rounded differently): one J v sweep at the start instead of one H*d sweep per breakpoint.  0: as the reference
- *   "cauchy_image_max_ma" [16] ... and with up to this many linear equalities (0..64): there the row-space form keeps a = J D g and
- *                        B = J D A' (rows x mA) next to J d, J s_c — 1 + mA J v sweeps up front, one column of J per breakpoint
- *                        afterwards; between this value and 64 rows the form is used when the previous search on the same bh_proj
- *                        took more than 4 (1 + mA) passes
+ *   "cauchy_image_max_ma" [64] ... and with up to this many linear equalities (0..64): there the row-space form keeps a = J D g and
+ *                        B = J D A' (rows x mA) next to J d, J s_c — two sweeps over J up front (a: J v; B: "cauchy_gemm"), one
+ *                        column of J per breakpoint afterwards; above this value and up to 64 rows the form is used when the
+ *                        previous search on the same bh_proj took more than 4 (1 + mA) passes
+ *   "cauchy_gemm"    [1] B = J D A' in ONE sweep over J on the fp64 matrix cores (a tall-skinny GEMM: M = rows of J, N = mA, K = n);
+ *                        0: mA J v sweeps over the masked rows of A
  *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)
  *   "gram_mfma"      [1] A_free A_free' on fp64 MFMA when mA > 96 (2: always, 0: never)
  *   "rs_variant"     [0] A/B geometries of the row-streaming kernel for 2048 < n <= 4096 (tools/kernel_ab.py)

@@ -966,10 +966,47 @@ def test_cauchy_step_in_the_row_space_of_j(bh, capsys, d, n, q, nact, delta_scal
     H.close()
 
 
+@pytest.mark.parametrize("d,n,mA,q", [(500, 200, 5, 0), (600, 257, 33, 2), (300, 270, 64, 0), (65, 70, 17, 1)])
+def test_cauchy_row_space_setup_on_the_matrix_cores(bh, d, n, mA, q):
+    """B = J D A' of the row-space Cauchy search with linear equalities: one sweep over J on the fp64 matrix cores
+    (image_b_mfma_kernel, option cauchy_gemm) against mA J v sweeps over the masked rows of A (cauchy_gemm = 0) and against the
+    oracle: same final active set, steps to 1e-9; odd sizes on every side (rows not a multiple of 16, mA not a multiple of 16,
+    n just above a padding boundary, nonlinear-constraint rows)."""
+    rng = np.random.default_rng(d + n + mA)
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    A = rng.standard_normal((mA, n))
+    L0 = R.chol_lower(A @ A.T)
+    xlow, xupp = -np.ones(n), np.ones(n)
+    x = np.clip(0.5 * rng.standard_normal(n), -0.95, 0.95)
+    x[rng.choice(n, n // 20, replace=False)] = 1.0
+    g = 200.0 * rng.standard_normal(n)
+    delta = 0.5 * np.linalg.norm(g)
+    Ho = R.AlHessian(J, C, 4.0)
+    cons_o = R.make_mixed_constraints(A, L0, l=xlow, u=xupp)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, R.NumpyOps())
+    H = bh.AlHessian(J, C, 4.0)
+    out = {}
+    for gemm in (1, 0):
+        bh.set_option("cauchy_gemm", gemm)
+        try:
+            cons = bh.MixedConstraints(A, None, l=xlow, u=xupp)
+            s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+        finally:
+            bh.set_option("cauchy_gemm", 1)
+        assert np.array_equal(cons.fixvars, cons_o.fixvars), gemm
+        note_tol("cauchy_step (equalities, row-space form): step vs oracle, 1e-9", relnorm(s, s_ref), 1e-9, "gemm=%d d=%d n=%d mA=%d, %d breakpoints" % (gemm, d, n, mA, info["n_breakpoints"]))
+        assert relnorm(s, s_ref) <= 1e-9, (gemm, relnorm(s, s_ref))
+        out[gemm] = s
+        cons.close()
+    assert relnorm(out[1], out[0]) <= 1e-9
+    H.close()
+
+
 def test_cauchy_step_row_space_form_chosen_from_history(bh, capsys):
-    """Between 17 and 64 linear equalities the row-space form of the Cauchy search (1 + mA J v sweeps up front) is used when the
-    previous search on the same handle took more than 4 (1 + mA) passes: first call sweeping (one H*d per breakpoint), second call
-    in the row space (no H*d) — both against the oracle: same active set, step to 1e-9."""
+    """Above cauchy_image_max_ma linear equalities (default 64; 16 here) and up to 64 the row-space form of the Cauchy search is used
+    when the previous search on the same handle took more than 4 (1 + mA) passes: first call sweeping (one H*d per breakpoint),
+    second call in the row space (no H*d) — both against the oracle: same active set, step to 1e-9."""
     rng = np.random.default_rng(77)
     d, n, mA = 900, 400, 20
     J = rng.standard_normal((d, n)) / np.sqrt(d)
@@ -985,12 +1022,16 @@ def test_cauchy_step_row_space_form_chosen_from_history(bh, capsys):
     H = bh.AlHessian(J, None, 10.0)
     cons = bh.MixedConstraints(A, None, l=xlow, u=xupp)
     swept = []
-    for call in range(2):
-        n0 = H.stats()["n_hmul"]
-        s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
-        swept.append(H.stats()["n_hmul"] - n0)
-        assert np.array_equal(cons.fixvars, cons_o.fixvars), call
-        assert relnorm(s, s_ref) <= 1e-9, (call, relnorm(s, s_ref))
+    bh.set_option("cauchy_image_max_ma", 16)        # (default 64: the form would be unconditional at mA = 20)
+    try:
+        for call in range(2):
+            n0 = H.stats()["n_hmul"]
+            s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+            swept.append(H.stats()["n_hmul"] - n0)
+            assert np.array_equal(cons.fixvars, cons_o.fixvars), call
+            assert relnorm(s, s_ref) <= 1e-9, (call, relnorm(s, s_ref))
+    finally:
+        bh.set_option("cauchy_image_max_ma", 64)
     with capsys.disabled():
         print("[Cauchy search, mA = 20] %d passes; H*d sweeps: first call %d, second call %d (row-space form chosen from history)"
               % (info["n_hmul"], swept[0], swept[1]))
