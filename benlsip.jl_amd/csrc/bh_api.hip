@@ -3030,7 +3030,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                         H->stats.n_jv += 1;
                     }
                     if (gemm) {
-                        hipLaunchKernelGGL(image_b_mfma_kernel, dim3((unsigned)((img_rows + 63) / 64)), dim3(256), 0, s, (const double*)H->Jd, H->ld,
+                        hipLaunchKernelGGL(image_b_mfma_kernel, dim3((unsigned)((img_rows + 127) / 128)), dim3(256), 0, s, (const double*)H->Jd, H->ld,
                                            img_rows, (const double*)P->Ad, P->ldA, mA, (const int*)P->fixrank, H->timg_gen + rows_cap, rows_cap);
                         BH_HIP(hipGetLastError());
                     }

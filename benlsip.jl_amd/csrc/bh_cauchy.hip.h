@@ -99,60 +99,94 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs 
 }
 
 // B = J~ D A'  (rows x mA, column j at B + j * rows_cap) on the matrix cores: the one place on this path where a tile of J meets a
-// dense GEMM (M = rows of J, N = mA <= 64, K = n) — 1 + mA J v sweeps became one sweep.  v_mfma_f64_16x16x4_f64; a wave owns a
-// strip of 16 rows of J and all four 16-column tiles of the output; the K index is permuted as in gram_free_mfma_kernel (lane group
-// l >> 4 owns 4 consecutive columns of every 16-column super-step: one 32-byte load per lane and operand, 128 contiguous bytes per
-// matrix row); two accumulation chains per tile; fixed variables are masked out of the A operand (D).  Fixed order: bit-reproducible.
+// dense GEMM (M = rows of J, N = mA <= 64, K = n) — 1 + mA J v sweeps became two.  v_mfma_f64_16x16x4_f64; a workgroup of four waves
+// owns 128 rows of J (a wave 32 of them: two 16-row tiles x four 16-column output tiles); the K index is permuted as in
+// gram_free_mfma_kernel (lane group l >> 4 owns 4 consecutive columns of every 16-column super-step: one 32-byte load per lane and
+// operand, 128 contiguous bytes per matrix row).  The masked 64 x 16 tile of A of a super-step is fetched ONCE per workgroup (wave
+// w loads output tile w's 16 rows) and handed to the other waves through a double-buffered LDS slot — read by every wave
+// straight from L2 it was 4/5 of the kernel's traffic (10 GiB through L2 for 2 GiB of J: 1.4 ms at config-5 size).
+// Fixed order of accumulation: bit-reproducible.
 __global__ __launch_bounds__(256) void image_b_mfma_kernel(const double* __restrict__ J, int64_t ld, int64_t nrows, const double* __restrict__ A,
                                                            int64_t ldA, int mA, const int* __restrict__ fixrank, double* __restrict__ B,
                                                            int64_t rows_cap) {
+    __shared__ double2 atile[2][4][2][64];            // [buffer][output tile][column pair 01 / 23][lane]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t strip = ((int64_t)blockIdx.x * 4 + wave) * 16;
-    if (strip >= nrows) return;
+    const int64_t strip = ((int64_t)blockIdx.x * 4 + wave) * 32;         // (waves past the last row still take part in the barriers)
     const int ri = lane & 15, kq = lane >> 4;
-    const bool vrow = strip + ri < nrows;
-    const double* pj = J + (vrow ? strip + ri : 0) * ld + 4 * kq;
-    const double* pa[4];
-    bool va[4];
+    const double* pj[2];
+    bool vrow[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        va[t] = 16 * t + ri < mA;
-        pa[t] = A + (int64_t)(va[t] ? 16 * t + ri : 0) * ldA + 4 * kq;
+    for (int m = 0; m < 2; ++m) {
+        vrow[m] = strip + 16 * m + ri < nrows;
+        pj[m] = J + (vrow[m] ? strip + 16 * m + ri : 0) * ld + 4 * kq;
     }
-    dvec4 acc0[4], acc1[4];
+    const bool va = 16 * wave + ri < mA;               // this wave fetches rows 16 wave .. 16 wave + 15 of A (output tile `wave`)
+    const double* pa = A + (int64_t)(va ? 16 * wave + ri : 0) * ldA + 4 * kq;
+    dvec4 acc[2][4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { acc0[t] = dvec4{0.0, 0.0, 0.0, 0.0}; acc1[t] = dvec4{0.0, 0.0, 0.0, 0.0}; }
-    const int nsuper = (int)(ld >> 4);               // ld (= ldA) is a multiple of 16; the padding columns of both images are zero
-#pragma unroll 2
-    for (int sidx = 0; sidx < nsuper; ++sidx) {
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = dvec4{0.0, 0.0, 0.0, 0.0};
+    const int nsuper = (int)(ld >> 4);                 // ld (= ldA) is a multiple of 16; the padding columns of both images are zero
+    auto fetch_a = [&](int sidx, double2& a01, double2& a23) {
         const int64_t c = (int64_t)sidx * 16;
-        double2 j01 = make_double2(0.0, 0.0), j23 = j01;
-        if (vrow) { j01 = *reinterpret_cast<const double2*>(pj + c); j23 = *reinterpret_cast<const double2*>(pj + c + 2); }
-        int4 f = make_int4(-1, -1, -1, -1);
-        if (fixrank != nullptr) f = *reinterpret_cast<const int4*>(fixrank + c + 4 * kq);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            double2 a01 = make_double2(0.0, 0.0), a23 = a01;
-            if (va[t]) { a01 = *reinterpret_cast<const double2*>(pa[t] + c); a23 = *reinterpret_cast<const double2*>(pa[t] + c + 2); }
+        a01 = a23 = make_double2(0.0, 0.0);
+        if (va) { a01 = *reinterpret_cast<const double2*>(pa + c); a23 = *reinterpret_cast<const double2*>(pa + c + 2); }
+        if (fixrank != nullptr) {
+            const int4 f = *reinterpret_cast<const int4*>(fixrank + c + 4 * kq);
             if (f.x >= 0) a01.x = 0.0;
             if (f.y >= 0) a01.y = 0.0;
             if (f.z >= 0) a23.x = 0.0;
             if (f.w >= 0) a23.y = 0.0;
-            acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j01.x, a01.x, acc0[t], 0, 0, 0);
-            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j01.y, a01.y, acc1[t], 0, 0, 0);
-            acc0[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j23.x, a23.x, acc0[t], 0, 0, 0);
-            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j23.y, a23.y, acc1[t], 0, 0, 0);
         }
+    };
+    auto fetch_j = [&](int sidx, double2 (&j01)[2], double2 (&j23)[2]) {
+        const int64_t c = (int64_t)sidx * 16;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            j01[m] = j23[m] = make_double2(0.0, 0.0);
+            if (vrow[m]) { j01[m] = *reinterpret_cast<const double2*>(pj[m] + c); j23[m] = *reinterpret_cast<const double2*>(pj[m] + c + 2); }
+        }
+    };
+    double2 na01, na23, nj01[2], nj23[2];
+    fetch_a(0, na01, na23);
+    fetch_j(0, nj01, nj23);
+    atile[0][wave][0][lane] = na01; atile[0][wave][1][lane] = na23;
+    __syncthreads();
+    for (int sidx = 0; sidx < nsuper; ++sidx) {
+        const int buf = sidx & 1;
+        double2 j01[2], j23[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { j01[m] = nj01[m]; j23[m] = nj23[m]; }
+        if (sidx + 1 < nsuper) {                                           // next super-step's operands: in flight during the MFMAs
+            fetch_a(sidx + 1, na01, na23);
+            fetch_j(sidx + 1, nj01, nj23);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double2 a01 = atile[buf][t][0][lane], a23 = atile[buf][t][1][lane];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j01[m].x, a01.x, acc[m][t], 0, 0, 0);
+                acc[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j01[m].y, a01.y, acc[m][t], 0, 0, 0);
+                acc[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j23[m].x, a23.x, acc[m][t], 0, 0, 0);
+                acc[m][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(j23[m].y, a23.y, acc[m][t], 0, 0, 0);
+            }
+        }
+        if (sidx + 1 < nsuper) { atile[buf ^ 1][wave][0][lane] = na01; atile[buf ^ 1][wave][1][lane] = na23; }
+        __syncthreads();                                                   // one barrier per super-step (the slot written is the other one)
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = 16 * t + (lane & 15);
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = strip + (lane >> 4) + 4 * r;
-            if (col < mA && row < nrows) B[(int64_t)col * rows_cap + row] = acc0[t][r] + acc1[t][r];
+        for (int t = 0; t < 4; ++t) {
+            const int col = 16 * t + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = strip + 16 * m + (lane >> 4) + 4 * r;
+                if (col < mA && row < nrows) B[(int64_t)col * rows_cap + row] = acc[m][t][r];
+            }
         }
-    }
 }
 
 // Several ranks: this rank's two sums (its rows of J) in scal[0..1], ready for the all-reduce that precedes the advance kernel.
