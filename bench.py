@@ -318,18 +318,38 @@ def main():
         # Both transports are brought up when possible: RCCL (BASELINE's north_star names it) and the library's one-shot
         # peer-buffer exchange.  The K timed steps run on each; which run is the headline is decided below (valid and faster).
         bcast = bh.torch_broadcast_bytes(None if (rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo") else torch.device("cuda", local_rank))
-        user_choice = "BH_COMM" in os.environ
-        os.environ.setdefault("BH_COMM", "both")
+        user_choice = os.environ.get("BH_COMM", "auto") != "auto"      # BH_COMM=auto (or unset): walk the list below
         os.environ.setdefault("BH_PEER_TIMEOUT_S", "5")      # a peer exchange that does not work must not eat the run's time budget
-        try:
-            bh.init_distributed(rank, world, bcast)
-        except bh.BenlsipHipError as e:
-            if user_choice:
-                raise
-            # the handle exchange fails on every rank or on none (shared flag + barriers): all ranks take this branch together
-            comm_note = "peer-buffer transport unavailable (%s); RCCL only" % e
-            os.environ["BH_COMM"] = "rccl"
-            bh.init_distributed(rank, world, bcast)
+        pg_dev = "cpu" if (rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo") else "cuda"
+
+        def bring_up(mode):
+            """bh_comm_init with BH_COMM = mode on every rank; the verdict is taken TOGETHER (a rank whose own init worked tears it
+            down again when a peer's did not), so all ranks walk down the same list of fall-backs."""
+            os.environ["BH_COMM"] = mode
+            err = None
+            try:
+                bh.init_distributed(rank, world, bcast)
+            except bh.BenlsipHipError as e:
+                err = str(e)
+            flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            if flag.item() > 0:
+                if err is None:
+                    bh._lib.lib().bh_comm_destroy()
+                return err or "bh_comm_init failed on %d other rank(s)" % int(flag.item())
+            return None
+
+        # default: both transports; if that cannot be had, RCCL alone (what the north_star names), then the peer buffers alone
+        notes = []
+        for mode in ([os.environ["BH_COMM"]] if user_choice else ["both", "rccl", "ipc"]):
+            err = bring_up(mode)
+            if err is None:
+                break
+            notes.append("BH_COMM=%s: %s" % (mode, err))
+        else:
+            raise SystemExit("bench: no communicator could be brought up: " + " | ".join(notes))
+        if notes:
+            comm_note = "fell back to BH_COMM=%s (%s)" % (os.environ["BH_COMM"], " | ".join(notes))
     elif dist is not None:
         bh.init_distributed(rank, world, bh.torch_broadcast_bytes(None if (rehearsal or os.environ.get("BH_BENCH_PG", "nccl") == "gloo") else torch.device("cuda", local_rank)))
     comm_mode = os.environ.get("BH_COMM", "rccl") if world > 1 else None

@@ -33,14 +33,20 @@ def init_distributed(rank, nranks, broadcast_bytes):
     if nranks == 1 and os.environ.get("BH_FORCE_COMM", "0") in ("", "0"):
         check(lib.bh_comm_init(0, 1, None), "bh_comm_init")
         return
-    buf = None
+    buf, rc0 = None, 0
     if rank == 0:
         raw = (C.c_ubyte * _lib.BH_UNIQUE_ID_BYTES)()
-        check(lib.bh_comm_unique_id(raw), "bh_comm_unique_id")
-        buf = bytes(raw)
+        rc0 = lib.bh_comm_unique_id(raw)
+        # a failure here must not leave the other ranks waiting in the broadcast: an all-zero id tells them (no transport
+        # produces one: RCCL ids carry a socket address, peer-buffer ids 64 random bytes)
+        buf = bytes(raw) if rc0 == 0 else bytes(_lib.BH_UNIQUE_ID_BYTES)
     buf = broadcast_bytes(buf)
     if len(buf) != _lib.BH_UNIQUE_ID_BYTES:
         raise ValueError("unique id must be %d bytes" % _lib.BH_UNIQUE_ID_BYTES)
+    if rank == 0 and rc0 != 0:
+        check(rc0, "bh_comm_unique_id")
+    if not any(buf):
+        raise _lib.BenlsipHipError(_lib.BH_ERR_RCCL, "bh_comm_unique_id", "rank 0 could not create the communicator id")
     raw = (C.c_ubyte * _lib.BH_UNIQUE_ID_BYTES).from_buffer_copy(buf)
     check(lib.bh_comm_init(rank, nranks, raw), "bh_comm_init")
 

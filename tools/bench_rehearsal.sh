@@ -11,10 +11,12 @@ export BH_BENCH_REHEARSAL=1
 rc=0
 #   3. the same with rank 1 staying away from the peer exchange (BH_BENCH_FAULT_RANK): rank 0 runs into the exchange's timeout;
 #      the line must still be printed, with comm.error set and no rank left behind in a collective.
-for cfg in "2 weak ipc" "3 strong ipc" "2 weak both" "2 weak both fault"; do
+#   4. BH_COMM=auto with the real RCCL: it refuses two ranks on one device, on every rank, so the script must walk
+#      both -> rccl -> ipc together and finish on the peer buffers with the fall-backs recorded in comm.note.
+for cfg in "2 weak ipc" "3 strong ipc" "2 weak both" "2 weak both fault" "2 weak auto"; do
     set -- $cfg
     export BH_COMM=$3
-    unset BH_BENCH_FAULT_RANK BH_PEER_TIMEOUT_S
+    unset BH_BENCH_FAULT_RANK BH_PEER_TIMEOUT_S BH_RCCL_LIB BH_STAGED_RCCL_SHM
     if [ "$4" = "fault" ]; then export BH_BENCH_FAULT_RANK=1 BH_PEER_TIMEOUT_S=3; fi
     if [ "$3" = "both" ]; then
         g++ -O2 -fPIC -shared -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/multirank/staged_rccl.cpp \
@@ -30,6 +32,7 @@ for cfg in "2 weak ipc" "3 strong ipc" "2 weak both" "2 weak both fault"; do
     fi
     rm -f /dev/shm/bh_rehearsal_$$
     tail -1 gpurun_out/bench_rehearsal_$1_$2_$3$4.log | cut -c1-1200
+    if [ "$3" = "auto" ]; then grep -q 'fell back to BH_COMM=ipc' gpurun_out/bench_rehearsal_$1_$2_$3$4.log || { echo "auto: no fall-back note"; rc=1; }; fi
     grep -o '"comm": {[^}]*}[^}]*}' gpurun_out/bench_rehearsal_$1_$2_$3$4.log | cut -c1-900
     [ $rc -eq 0 ] || { tail -30 gpurun_out/bench_rehearsal_$1_$2_$3$4.log; exit $rc; }
 done
