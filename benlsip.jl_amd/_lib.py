@@ -41,7 +41,8 @@ class bh_stats_t(C.Structure):
     _fields_ = [("n_hmul", C.c_int64), ("n_jv", C.c_int64), ("n_jtv", C.c_int64), ("n_proj", C.c_int64),
                 ("n_pcg", C.c_int64), ("n_cg_iter", C.c_int64), ("n_allreduce", C.c_int64), ("hmul_ms", C.c_double),
                 ("hmul_timed", C.c_int64), ("bytes_per_hmul", C.c_double),
-                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("h2d_calls", C.c_int64), ("d2h_calls", C.c_int64)]
+                ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("h2d_calls", C.c_int64), ("d2h_calls", C.c_int64),
+                ("cg_kernels", C.c_int64)]
 
 
 _dp = C.POINTER(C.c_double)

@@ -2151,13 +2151,18 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // then left_mul_tr.  Both change pHp's rounding like the box form does (cg_fused = 0 keeps dot(p, H*p)).
     const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 1 && P->reduced && P->mA <= 64 && P->tpart != nullptr && P->ldA == H->ld;
     const bool gen_linv = fuse_gen && g_ctx.opt_cg_fused == 1 && P->W != nullptr;
-    // Several ranks: the two-kernel form carries the exchange inside the update kernel when the peer-buffer transport is the
-    // active one (cg_reduce_update_kernel<false, true>: push the workgroup's 32 columns + its rank's share of pHp, wait, sum in
+    // Several ranks: the two-kernel (equalities: three-kernel) form carries the exchange inside the update kernel when the
+    // peer-buffer transport is the active one (cg_reduce_update_kernel<GEN, true>: push the workgroup's 32 columns + its rank's share of pHp, wait, sum in
     // rank order); an RCCL all-reduce cannot sit inside a kernel, so that path keeps the three-kernel form.
-    const bool peer_fused = comm_active() && use_peer_path() && box && (H->nchunks + 15) / 16 <= kPeerBlkCap;
-    if ((box || fuse_gen) && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && (!comm_active() || peer_fused) && max_iter >= 1 &&
+    const bool peer_fused = comm_active() && use_peer_path() && (box || fuse_gen) && (H->nchunks + 15) / 16 <= kPeerBlkCap;
+    // Equalities over RCCL: the collective is enqueued by the host between the slab reduction (which packs this rank's share of
+    // p'Hp behind the vector, as in the box form below) and the update kernel, which then sums ONE slab — the all-reduced H*p:
+    //   S(1) | R(1) AR(1) U(1) P(1) S(2) | ...   four kernels + the collective instead of seven, on the lock-step launch schedule.
+    const bool rccl_gen = comm_active() && !use_peer_path() && fuse_gen;
+    if ((box || fuse_gen) && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp_supported(rs_cfg) && (!comm_active() || peer_fused || rccl_gen) && max_iter >= 1 &&
         (gp == c.g || n == n_pad)) {
         BH_TRY(hess_ready(H));
+        H->stats.cg_kernels = (box ? 2 : (gen_linv ? 3 : 4)) + (rccl_gen ? 1 : 0);
         if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
         const int64_t nrows = H->d + H->q_eff;
         const int grid = grid_for(rs_cfg, nrows);
@@ -2208,32 +2213,39 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             if (slot >= 0) BH_HIP(hipEventRecord(H->ev[2 * slot + 1], s));
             return BH_OK;
         };
-        auto launch_update = [&](int j) {
+        auto launch_update = [&](int j) -> int32_t {
             CgUpdArgs u{};
-            u.st = c.d_state; u.j = j; u.partials = H->partials; u.ld = H->ld; u.nchunks = H->nchunks; u.G = grid;
+            u.st = c.d_state; u.j = j; u.partials = H->partials; u.ld = H->ld; u.nchunks = H->nchunks; u.G = grid; u.Gs = grid; u.Gq = grid;
             u.sqpart = H->sq_partials; u.gpart = H->sq_partials + H->g_cap; u.rvpart_in = rvbuf[(j - 1) & 1]; u.rvpart_out = rvbuf[j & 1]; u.nrv = nrv;
             u.p = pbuf[j & 1]; u.w = wp; u.hw = hw; u.r = c.r; u.g = gp; u.v = c.v; u.fixrank = a.fixrank;
             u.n = (int)n; u.atol_neg = atol_negcurv; u.trace = a.trace; u.trace_cap = a.trace_cap; u.mirror = a.mirror; u.tag = a.tag;
-            if (peer_fused) {
-                hipLaunchKernelGGL((cg_reduce_update_kernel<false, true>), dim3(nblk), dim3(256), 0, s, u, g_ctx.peer.args);
-                return;
-            }
             if (!fuse_gen) {
-                hipLaunchKernelGGL((cg_reduce_update_kernel<false, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
-                return;
+                if (peer_fused) hipLaunchKernelGGL((cg_reduce_update_kernel<false, true>), dim3(nblk), dim3(256), 0, s, u, g_ctx.peer.args);
+                else hipLaunchKernelGGL((cg_reduce_update_kernel<false, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
+                return BH_OK;
             }
+            if (rccl_gen) {
+                hipLaunchKernelGGL(reduce_partials_sq_kernel, dim3(nblk), dim3(256), 0, s, (const double*)H->partials, H->ld, H->nchunks, grid,
+                                   c.hpx, (const double*)H->sq_partials, (int)n_pad, (const CgState*)c.d_state, j);
+                BH_HIP(hipGetLastError());
+                BH_TRY(allreduce_inplace(c.hpx, n_pad + 2, H));
+                u.partials = c.hpx; u.Gs = 1; u.sqpart = c.hpx + n_pad; u.Gq = 1;
+            }
+            // (A, L and the vectors are replicated: past the exchange every rank forms the same partials of A_free r, the same v)
             u.A = P->Ad; u.ldA = P->ldA; u.mA = (int)P->mA; u.tpart = P->tpart; u.init_in_memory = gen_linv ? 0 : 1;
-            hipLaunchKernelGGL((cg_reduce_update_kernel<true, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
+            if (peer_fused) hipLaunchKernelGGL((cg_reduce_update_kernel<true, true>), dim3(nblk), dim3(256), 0, s, u, g_ctx.peer.args);
+            else hipLaunchKernelGGL((cg_reduce_update_kernel<true, false>), dim3(nblk), dim3(256), 0, s, u, PeerArgs{});
             // y = (A_free A_free')^{-1} (A_free r): partial sums + the two triangular solves; then v = r_free - A_free'y and r.v
             ProjArgs pa = proj_args(P, c.d_state, true);
             pa.tpart = P->tpart; pa.tpart_nblk = nblk; pa.rvpart = rvbuf[j & 1]; pa.fused_j = j;
             if (gen_linv) {
                 pa.W = P->W; pa.nch_pad = H->nchunks;
                 hipLaunchKernelGGL((proj_apply_linv_kernel<false>), dim3((unsigned)nrv), dim3(256), 0, s, pa, (const double*)c.r, c.v);
-                return;
+                return BH_OK;
             }
             hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
             hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 4>), dim3((nch_v + 63) / 64), dim3(256), 0, s, pa, (const double*)c.r, c.v);
+            return BH_OK;
         };
         // Launch order: S(1) | U(1) S(2) | U(2) S(3) | ...: the stream kernel of iteration j+1 is what detects "solved" after
         // iteration j, so it is always enqueued together with U(j) (as a gated no-op if the loop ended in U(j)).
@@ -2242,7 +2254,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         auto launch_batch = [&](int nb) -> int32_t {
             nb = std::min(nb, max_iter - launched);
             for (int i = 0; i < nb; ++i) {
-                launch_update(launched + 1);
+                BH_TRY(launch_update(launched + 1));
                 BH_TRY(launch_stream(launched + 2));               // (iteration max_iter + 1 only ever runs its prologue: iter > max_iter)
                 launched += 1;
             }
@@ -2251,8 +2263,31 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
         };
         const int batch = launch_batch_size(H);
         MirrorWord mw{};
-        const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : std::min(batch, 2);
         constexpr int kNever = 0x7fffffff;
+        if (rccl_gen) {
+            // every enqueued iteration holds a collective: all ranks must take the same launch decisions, so a decision taken after
+            // S(target + 1) has spoken uses "the loop had ended by iteration `target`" only, never a later state one rank happened
+            // to see (the lock-step schedule of the separate-kernel form, on this form's progress protocol)
+            auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
+            BH_TRY(launch_batch(H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : 1));
+            BH_TRY(wait_mirror(c, a.tag, kNever, &mw, launched + 1));
+            if (!done_by(launched) && launched < max_iter) {
+                BH_TRY(launch_batch(batch));
+                while (true) {
+                    const int target = launched;
+                    const bool more = launched < max_iter;
+                    if (more) BH_TRY(launch_batch(batch));
+                    BH_TRY(wait_mirror(c, a.tag, kNever, &mw, target + 1));
+                    if (done_by(target) || !more) break;
+                }
+            }
+            BH_TRY(wait_mirror(c, a.tag, kNever, &mw));
+            if (!mw.done) return fail(BH_ERR_HIP, "internal: CG loop did not terminate");
+            fin_out->done = mw.done; fin_out->status = mw.status; fin_out->iter = mw.iter; fin_out->n_hmul = mw.n_hmul;
+            fin_out->tag = a.tag;             // (results_final stays false: over-launched collectives are still in flight)
+            return BH_OK;
+        }
+        const int first = H->last_n_hmul > 0 ? std::min(H->last_n_hmul, kFirstBatchCap) : std::min(batch, 2);
         BH_TRY(launch_batch(first));
         // S(launched + 1) speaks for iteration `launched`: either "stopped" (done) or "iter = launched + 1, streaming"
         BH_TRY(wait_mirror(c, a.tag, kNever, &mw, launched + 1));
@@ -2284,8 +2319,10 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // The launch schedule is the lock-step one of the three-kernel form below (decisions on "done by iteration k" only).
     const bool rccl_fused = comm_active() && !use_peer_path() && box && g_ctx.opt_cg_fused && rs_cfg >= 0 && cgp3_supported(rs_cfg) &&
                             max_iter >= 1 && (gp == c.g || n == n_pad);
+    H->stats.cg_kernels = 0;
     if (rccl_fused) {
         BH_TRY(hess_ready(H));
+        H->stats.cg_kernels = 2;
         if (gp == c.g && n < n_pad && !g_pad_zeroed) BH_HIP(hipMemsetAsync(c.g + n, 0, (size_t)(n_pad - n) * sizeof(double), s));
         const int64_t nrows = H->d + H->q_eff;
         const int grid = grid_for(rs_cfg, nrows);

@@ -27,7 +27,8 @@ struct CgUpdArgs {
     CgState* st;
     int j;                          // iteration (1-based) = number of the H*p product being consumed
     const double* partials; int64_t ld; int nchunks; int G;      // slabs of the preceding row_stream launch
-    const double* sqpart;           // [G]
+    int Gs, Gq;                     // how many slabs / p'Hp partials to sum: G, or 1 when an all-reduced H*p with its p'Hp slot takes their place (RCCL)
+    const double* sqpart;           // [Gq]
     const double* gpart;            // [G]
     const double* rvpart_in;        // [nrv] partials of r.v from iteration j-1   (j >= 2)
     double* rvpart_out;             // [gridDim.x]
@@ -87,13 +88,13 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
     const int max_iter = st->max_iter;
     const double rtv_state = st->rtv;                          // j == 1: written by the H*p launch
     LaneBatch<8> b_sq, b_gp, b_rv;
-    b_sq.issue(a.sqpart, a.G);
+    b_sq.issue(a.sqpart, a.Gq);
     b_gp.issue(a.gpart, a.G);
     b_rv.issue(a.rvpart_in, a.nrv);                            // (j == 1: addressable, not used)
     const double2* P2 = reinterpret_cast<const double2*>(a.partials);
     const int cc = min(c, a.nchunks - 1);                      // out-of-range threads load a valid chunk and drop the result:
     SlabBatch sb;                                              // no branch around the loads (see LaneBatch::issue)
-    sb.issue(P2, ld2, cc, rl, a.G);
+    sb.issue(P2, ld2, cc, rl, a.Gs);
     // GEN: this thread's entries of A for the partials of A_free r below (rows rl, rl + 16, ...; up to 64 rows), asked for now
     double2 arow[4];
     if (GEN) {
@@ -105,11 +106,11 @@ __global__ __launch_bounds__(256) void cg_reduce_update_kernel(CgUpdArgs a, Peer
     if (upd && a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[c];   // last: its compare is scheduled next to it
 
     // ---- this workgroup's 32 columns of Hp = sum of the slabs (fixed order) --------------------------------------------
-    const double2 acc = sb.fold(P2, ld2, cc, rl, a.G);
+    const double2 acc = sb.fold(P2, ld2, cc, rl, a.Gs);
     sm[rl][cl] = acc;
 
     // ---- the iteration's scalars, recomputed by every wave from the partials (identical bits everywhere) -----------------
-    double pHp = wave_sum(b_sq.fold_sum(a.sqpart, a.G));                               // :723 (this rank's rows)
+    double pHp = wave_sum(b_sq.fold_sum(a.sqpart, a.Gq));                               // :723 (this rank's rows)
     if (PEER) {
         __shared__ int s_timeout;
         __shared__ double2 xs[kMaxPeers][16];

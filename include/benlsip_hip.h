@@ -79,6 +79,11 @@ typedef struct bh_stats_t {
      * host-pointer entry points, masks, factors, traces, J uploads; 8-byte scalars coming back through pinned memory are
      * included.  The *_dev entry points move none of the n-vectors they work on (tests check the difference of these counters). */
     int64_t h2d_bytes, d2h_bytes, h2d_calls, d2h_calls;
+    /* launch shape of the last bh_pcg on this handle: kernels per CG iteration in the fused forms, the collective not counted
+     * (box constraints 2, on one rank and over either transport; equalities 3 through the explicit factor inverse — 4 with
+     * cg_fused = 2 — on one rank and over the peer buffers, one more over RCCL: the slab reduction in front of ncclAllReduce);
+     * 0 = the separate-kernel forms (three kernels for box constraints, seven with equalities; option "cg_fused"). */
+    int64_t cg_kernels;
 } bh_stats_t;
 
 /* ---- library / device --------------------------------------------------- */

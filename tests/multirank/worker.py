@@ -63,6 +63,7 @@ def main():
     out["box_tight_w"], out["box_tight_st"], out["box_tight_it"], out["box_tight_nh"] = w, int(st), info["iters"], info["n_hmul"]
     w, st, info = bh.projected_cg(gm, H, np.where(fix, 0.0, -big), np.where(fix, 0.0, big), box, 3e-2, full_output=True)
     out["box_mid_w"], out["box_mid_st"], out["box_mid_it"] = w, int(st), info["iters"]
+    out["box_form"] = H.stats()["cg_kernels"]
     w, st, info = bh.projected_cg(gm, H, np.where(fix, 0.0, -big), np.where(fix, 0.0, big), box, 1e-3, full_output=True)
     # the same call again: the first batch is now sized by the previous call on this handle
     ar0 = H.stats()["n_allreduce"]
@@ -80,6 +81,7 @@ def main():
     gen = bh.MixedConstraints(A, None, fix, l=P["xlow"], u=P["xupp"])
     w, st, info = bh.projected_cg(gm, H, wl, wu, gen, 1e-6, full_output=True)
     out["gen_w"], out["gen_st"], out["gen_it"] = w, int(st), info["iters"]
+    out["gen_form"] = H.stats()["cg_kernels"]
     w, st, info = bh.minor_iterate(P["x"], P["s"], gm, H, gen, delta, 0.1, full_output=True)
     out["mi_w"], out["mi_st"], out["mi_alpha"] = w, int(st), info["alpha"]
 

@@ -136,6 +136,9 @@ def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     w, st, it = R.projected_cg(gm, Ho, z["wl"], z["wu"], gen, 1e-6)
     assert int(z["gen_st"]) == int(st) and int(z["gen_it"]) == it
     assert relnorm(z["gen_w"], w) <= 1e-9
+    # launch shapes: box constraints two kernels per iteration on either transport; with equalities three over the peer buffers
+    # (the exchange sits inside the update kernel) and four around a host-enqueued ncclAllReduce (slab reduction in front of it)
+    assert int(z["box_form"]) == 2 and int(z["gen_form"]) == (3 if comm == "ipc" else 4), (int(z["box_form"]), int(z["gen_form"]))
     delta = 0.1 * np.linalg.norm(z["g"])
     w, st = R.minor_iterate(P["x"], P["s"], gm, Ho, gen, delta, 0.1)
     assert int(z["mi_st"]) == int(st) and relnorm(z["mi_w"], w) <= 1e-9
