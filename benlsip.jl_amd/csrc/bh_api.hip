@@ -3066,7 +3066,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                         BH_TRY(launch_jv(H, H->vpad, H->timg_gen + (int64_t)(j + 1) * rows_cap, true, nullptr));
                         H->stats.n_jv += 1;
                     }
-                    if (gemm) {
+                    if (gemm && img_rows > 0) {                 // (a rank without rows has no rows of B)
                         hipLaunchKernelGGL(image_b_mfma_kernel, dim3((unsigned)((img_rows + 127) / 128)), dim3(256), 0, s, (const double*)H->Jd, H->ld,
                                            img_rows, (const double*)P->Ad, P->ldA, mA, (const int*)P->fixrank, H->timg_gen + rows_cap, rows_cap);
                         BH_HIP(hipGetLastError());

@@ -45,7 +45,23 @@ def main():
     vt = bh.vthv(H, g)
     cons = bh.MixedConstraints(np.zeros((0, n)), None, None)
     w, st, info = bh.projected_cg(g, H, -np.ones(n), np.ones(n), cons, 1e-3, full_output=True)
-    np.savez(os.path.join(workdir, "zero_rank%d.npz" % rank), hv=hv, vt=vt, w=w, st=int(st), it=info["iters"], lo=lo, hi=hi)
+    # linear equalities: projected_cg, a minor iterate, and the Cauchy search (row-space form: the rank without rows contributes
+    # nothing to the two sums and launches no GEMM for its empty block of B); box-constrained Cauchy search as well
+    A = rng.standard_normal((2, n))
+    xl, xu = -np.ones(n), np.ones(n)
+    x = np.clip(0.3 * rng.standard_normal(n), -0.9, 0.9)
+    gen = bh.MixedConstraints(A, None, None, l=xl, u=xu)
+    wg, stg, infog = bh.projected_cg(g, H, -0.5 * np.ones(n), 0.5 * np.ones(n), gen, 1e-6, full_output=True)
+    gen_kernels = H.stats()["cg_kernels"]
+    wm, stm, infom = bh.minor_iterate(x, np.zeros(n), g, H, gen, 0.5 * np.linalg.norm(g), 0.1, full_output=True)
+    cau = bh.MixedConstraints(A, None, None, l=xl, u=xu)
+    sc, infoc = bh.cauchy_step(x, 50.0 * g, H, cau, 25.0 * np.linalg.norm(g), full_output=True)
+    caub = bh.MixedConstraints(np.zeros((0, n)), None, None, l=xl, u=xu)
+    sb, infob = bh.cauchy_step(x, 50.0 * g, H, caub, 25.0 * np.linalg.norm(g), full_output=True)
+    np.savez(os.path.join(workdir, "zero_rank%d.npz" % rank), hv=hv, vt=vt, w=w, st=int(st), it=info["iters"], lo=lo, hi=hi,
+             A=A, x=x, wg=wg, stg=int(stg), itg=infog["iters"], gen_kernels=gen_kernels, wm=wm, stm=int(stm),
+             sc=sc, sc_fix=np.asarray(cau.fixvars, dtype=bool), sc_passes=infoc["n_hmul"],
+             sb=sb, sb_fix=np.asarray(caub.fixvars, dtype=bool), sb_passes=infob["n_hmul"])
     H.close()
     bh._lib.check(bh._lib.lib().bh_comm_destroy(), "bh_comm_destroy")
     print("rank %d rows [%d, %d) done" % (rank, lo, hi), flush=True)

@@ -203,7 +203,7 @@ def test_ranks_without_rows(tmp_path, comm):
     res = [np.load(os.path.join(tmp_path, "zero_rank%d.npz" % r)) for r in range(world)]
     assert int(res[2]["hi"]) - int(res[2]["lo"]) == 0
     for r in range(1, world):
-        for key in ("hv", "vt", "w", "st", "it"):
+        for key in ("hv", "vt", "w", "st", "it", "wg", "stg", "itg", "gen_kernels", "wm", "stm", "sc", "sc_fix", "sc_passes", "sb", "sb_fix", "sb_passes"):
             assert np.array_equal(res[0][key], res[r][key]), (r, key)
     rng = np.random.default_rng(5)
     J = rng.standard_normal((2, 24)); C = rng.standard_normal((1, 24)); g = rng.standard_normal(24)
@@ -212,6 +212,25 @@ def test_ranks_without_rows(tmp_path, comm):
     Z = np.zeros((0, 24))
     w, st, it = R.projected_cg(g, Ho, -np.ones(24), np.ones(24), R.make_mixed_constraints(Z, R.chol_lower(Z @ Z.T), None, l=-np.ones(24), u=np.ones(24)), 1e-3)
     assert int(res[0]["st"]) == int(st) and int(res[0]["it"]) == it and relnorm(res[0]["w"], w) <= 1e-8
+    # with linear equalities, and the Cauchy searches (the worker drew A and x after J, C, g from the same generator)
+    z, n = res[0], 24
+    A, x = z["A"], z["x"]
+    xl, xu = -np.ones(n), np.ones(n)
+    L0 = R.chol_lower(A @ A.T)
+    gen = R.make_mixed_constraints(A, L0, None, l=xl, u=xu)
+    w, st, it = R.projected_cg(g, Ho, -0.5 * np.ones(n), 0.5 * np.ones(n), gen, 1e-6)
+    assert int(z["stg"]) == int(st) and int(z["itg"]) == it and relnorm(z["wg"], w) <= 1e-8
+    assert int(z["gen_kernels"]) == (3 if comm == "ipc" else 4)
+    wm, stm = R.minor_iterate(x, np.zeros(n), g, Ho, gen, 0.5 * np.linalg.norm(g), 0.1)
+    assert int(z["stm"]) == int(stm) and relnorm(z["wm"], wm) <= 1e-8
+    cau = R.make_mixed_constraints(A, L0, l=xl, u=xu)
+    s_ref = R.cauchy_step(x, 50.0 * g, Ho, L0, cau, 25.0 * np.linalg.norm(g), R.NumpyOps())
+    assert np.array_equal(z["sc_fix"], cau.fixvars) and relnorm(z["sc"], s_ref) <= 1e-9 and int(z["sc_passes"]) >= 2
+    Zc = np.zeros((0, n))
+    caub = R.make_mixed_constraints(Zc, R.chol_lower(Zc @ Zc.T), l=xl, u=xu)
+    sb_ref = R.cauchy_step(x, 50.0 * g, Ho, R.chol_lower(Zc @ Zc.T), caub, 25.0 * np.linalg.norm(g), R.NumpyOps())
+    assert np.array_equal(z["sb_fix"], caub.fixvars) and relnorm(z["sb"], sb_ref) <= 1e-9 and int(z["sb_passes"]) >= 2
+    print("[ranks without rows, %s] Cauchy passes: %d with equalities, %d box" % (comm, int(z["sc_passes"]), int(z["sb_passes"])))
 
 
 def test_launch_schedule_is_rank_independent_at_a_batch_threshold(tmp_path):

@@ -1,30 +1,39 @@
-#!/usr/bin/env python3
-"""BASELINE config 2 (d=8192, n=1024, box, p=128): J = 64 MiB fits the 256 MiB Infinity Cache, so GB/s here is cache
-bandwidth ("effective"), never an HBM-roofline fraction."""
+"""BASELINE config 2 (m = 8192, n = 1024 fp64, box bounds) on one GPU: what a projected_cg subproblem and one CG iteration cost
+at a size where J (64 MiB) is re-read from the last-level cache and the iteration is launch- and latency-bound rather than
+HBM-bound.  Prints per-subproblem and per-iteration times for the well- and ill-conditioned variants and the kernel times of the
+stand-alone products.  Usage: python tools/config2_timing.py [d n]   (measurement tool; never imports the oracle)"""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import benlsip_jl_amd as bh  # noqa: E402
-import bench  # noqa: E402
 
 
 def main():
-    bh.init(0)
+    d = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    import benlsip_jl_amd as bh
+    import bench
+    bh.init(0, flags=bh._lib.BH_FLAG_PROFILE)
     for kind, name in ((0, "wc"), (1, "ic")):
-        H, cons, dv, host = bench.setup_instance(bh, 0, 1, kind, d_per_gpu=8192, n=1024)
-        bench.run_steps(bh, H, cons, dv, 0.1, 5)
-        bh._lib.lib().bh_synchronize()
-        t0 = time.perf_counter()
-        steps = 200
-        st, it, nh = bench.run_steps(bh, H, cons, dv, 0.1, steps)
-        el = (time.perf_counter() - t0) / steps
-        ms = [H.time_kernel(k, 50) for k in (0, 1, 2)]
-        gb = [8.0 * 8192 * 1024 / (m * 1e-3) / 1e9 for m in ms]
-        print("config2 %s: %s iters=%d n_hmul=%d  %.1f us per subproblem (%.0f/s), %.1f us per CG iteration; kernels fused/jv/jtv %s us = %s GB/s effective"
-              % (name, st.name, it, nh, 1e6 * el, 1 / el, 1e6 * el / max(nh, 1), ["%.1f" % (1e3 * m) for m in ms], ["%.0f" % g for g in gb]), flush=True)
+        for kappa2 in (0.1, 1e-3):
+            H, cons, dv, _ = bench.setup_instance(bh, 0, 1, kind, d_per_gpu=d, n=n)
+            bench.run_steps(bh, H, cons, dv, kappa2, 50)
+            bh._lib.lib().bh_synchronize()
+            reps = 200
+            t0 = time.perf_counter()
+            st, it, nh = bench.run_steps(bh, H, cons, dv, kappa2, reps)
+            bh._lib.lib().bh_synchronize()
+            el = (time.perf_counter() - t0) / reps
+            byt = H.stats()["bytes_per_hmul"]
+            print("%s kappa2 = %-6g %-22s %3d H*p: %8.1f us per subproblem, %6.2f us per H*p, %6.0f GB/s per iteration"
+                  % (name, kappa2, st.name, nh, 1e6 * el, 1e6 * el / max(nh, 1), byt / (el / max(nh, 1)) / 1e9), flush=True)
+            if kind == 0 and kappa2 == 0.1:
+                for k, label in ((0, "fused J'(W.(Jp))"), (1, "J v"), (2, "J'u"), (8, "slab reduction")):
+                    print("    kernel %-18s %7.2f us" % (label, 1e3 * H.time_kernel(k, 200)))
+            H.close()
+            cons.close()
 
 
 if __name__ == "__main__":
