@@ -374,3 +374,89 @@ def test_rccl_two_kernel_iteration_on_a_one_rank_communicator(capsys):
     with capsys.disabled():
         print("[RCCL two-kernel iteration, 1-rank communicator] " + out.stdout.strip().splitlines()[-1])
     assert out.stdout.strip().splitlines()[-1].startswith("OK")
+
+
+@pytest.mark.parametrize("comm,world,seed", [("ipc", 2, 31), ("ipc", 3, 32), ("staged", 2, 33), ("staged", 3, 34)])
+def test_multirank_fuzz_of_the_caller_level_entry_points(tmp_path, comm, world, seed):
+    """Seeded random instances (tests/multirank/fuzz_cases.py: odd and tiny n, fewer rows than ranks, rank-deficient H, q > 0, up to 20
+    linear equalities, fixed variables) through projected_cg, minor_iterate and cauchy_step with J row-sharded over 2-3 processes on
+    both transports: replicas bit-identical in every result, and equal to the oracle on the unsharded instance — exit status, iteration
+    and product counts, active set exactly; vectors to 1e-6 unless the ORACLE itself moves that much under a 1e-14 perturbation of J."""
+    from fuzz_cases import cases
+    count = 36
+    run_ranks("fuzz_worker.py", world, tmp_path, comm, extra=(str(seed), str(count)), timeout=600)
+    res = [np.load(os.path.join(tmp_path, "fuzz_rank%d.npz" % r)) for r in range(world)]
+    for r in range(1, world):
+        assert sorted(res[r].files) == sorted(res[0].files)
+        for key in res[0].files:
+            assert np.array_equal(res[0][key], res[r][key], equal_nan=True), "rank %d differs from rank 0 in %s" % (r, key)
+    z = res[0]
+    mism, n_cmp, n_sens, n_err, n_blown, shapes = [], 0, 0, 0, 0, set()
+    prng = np.random.default_rng(seed + 1000)
+    for c in cases(seed, count):
+        k, n, mA = c["k"], c["n"], c["mA"]
+        Ho = R.AlHessian(c["J"], c["C"], c["mu"])
+        Hp = R.AlHessian(c["J"] * (1 + 1e-14 * prng.standard_normal(c["J"].shape)), c["C"], c["mu"])
+        L0 = R.chol_lower(c["A"] @ c["A"].T)
+        fixed = c["fix"] if c["fix"].any() else None
+        if c["feasible_rows"]:
+            cons_o = R.make_mixed_constraints(c["A"], L0, fixed, l=c["xl"], u=c["xu"])
+            w, st, it = R.projected_cg(c["g"], Ho, c["wl"], c["wu"], cons_o, c["kappa2"])
+            dst, dit, dnh, kern = (int(v) for v in z["pcg_st_%d" % k])
+            shapes.add((mA > 0, kern))
+            n_cmp += 1
+            ok = (dst, dit) == (int(st), it) and (not np.all(np.isfinite(w)) or relnorm(z["pcg_w_%d" % k], w) <= 1e-6)
+            if not ok:
+                wp, stp, itp = R.projected_cg(c["g"], Hp, c["wl"], c["wu"], cons_o, c["kappa2"])
+                if (int(stp), itp) == (int(st), it) and (not np.all(np.isfinite(w)) or relnorm(wp, w) <= 1e-8):
+                    mism.append(("projected_cg", k, n, c["d"], c["q"], mA, dst, int(st), dit, it, relnorm(z["pcg_w_%d" % k], w)))
+                else:
+                    n_sens += 1
+            wm, stm = R.minor_iterate(c["x"], np.zeros(n), c["g"], Ho, cons_o, c["delta"], c["kappa2"])
+            n_cmp += 1
+            if not np.all(np.isfinite(wm)):
+                # minor_iterate leaves the free variables unbounded (:662-665); on a rank-deficient H the CG recurrence then grows without
+                # limit until rounding makes p'Hp negative and w += Inf * p (:727-729).  Which iteration that happens in is noise — the
+                # oracle's own scalars reach 1e37 first — so only "the device blew up too" (non-finite, or 1e15 times the gradient) is compared.
+                wd = z["mi_w_%d" % k]
+                assert not np.all(np.isfinite(wd)) or np.linalg.norm(wd) > 1e15 * (1.0 + np.linalg.norm(c["g"])), \
+                    ("minor_iterate: a bounded step on the device where the reference overflows", k, float(np.linalg.norm(wd)))
+                n_blown += 1
+                continue
+            ok = int(z["mi_st_%d" % k][0]) == int(stm) and relnorm(z["mi_w_%d" % k], wm) <= 1e-6
+            if not ok:
+                wq, stq = R.minor_iterate(c["x"], np.zeros(n), c["g"], Hp, cons_o, c["delta"], c["kappa2"])
+                if int(stq) == int(stm) and (not np.all(np.isfinite(wm)) or relnorm(wq, wm) <= 1e-8):
+                    mism.append(("minor_iterate", k, n, c["d"], c["q"], mA, int(z["mi_st_%d" % k][0]), int(stm), relnorm(z["mi_w_%d" % k], wm)))
+                else:
+                    n_sens += 1
+        cau = R.make_mixed_constraints(c["A"], L0, l=c["xl"], u=c["xu"])
+        try:
+            s_ref = R.cauchy_step(c["x"], c["g_cauchy"], Ho, L0, cau, c["delta"], R.NumpyOps())
+        except Exception:
+            s_ref = None
+        n_cmp += 1
+        if s_ref is None:
+            n_err += 1
+            if "cs_err_%d" % k not in z.files:          # the reference fails here: so must the device, on every rank
+                mism.append(("cauchy_step: the reference raises, the device returned a step", k, n, c["d"], mA))
+            continue
+        if "cs_err_%d" % k in z.files:
+            mism.append(("cauchy_step: device error %d where the reference returns a step" % int(z["cs_err_%d" % k][0]), k, n, c["d"], mA))
+            continue
+        ok = np.array_equal(z["cs_fix_%d" % k], cau.fixvars) and np.linalg.norm(z["cs_s_%d" % k] - s_ref) <= 1e-8 * max(np.linalg.norm(s_ref), 1e-300)
+        if not ok:
+            cau_p = R.make_mixed_constraints(c["A"], L0, l=c["xl"], u=c["xu"])
+            try:
+                s_p = R.cauchy_step(c["x"], c["g_cauchy"], Hp, L0, cau_p, c["delta"], R.NumpyOps())
+            except Exception:
+                s_p = None
+            if s_p is not None and np.array_equal(cau_p.fixvars, cau.fixvars) and np.linalg.norm(s_p - s_ref) <= 1e-9 * max(np.linalg.norm(s_ref), 1e-300):
+                mism.append(("cauchy_step", k, n, c["d"], c["q"], mA, int((z["cs_fix_%d" % k] != cau.fixvars).sum()),
+                             float(np.linalg.norm(z["cs_s_%d" % k] - s_ref) / max(np.linalg.norm(s_ref), 1e-300))))
+            else:
+                n_sens += 1
+    print("[multirank fuzz %s x%d] %d comparisons, %d left aside as rounding-sensitive in the oracle itself, %d reference failures and "
+          "%d overflowing minor iterates reproduced, CG launch shapes seen (equalities, kernels): %s" % (comm, world, n_cmp, n_sens, n_err, n_blown, sorted(shapes)))
+    assert not mism, "\n".join(str(m) for m in mism)
+    assert n_sens <= n_cmp // 5
