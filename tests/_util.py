@@ -323,3 +323,61 @@ def assert_iters_in_oracle_band(iters, band, label, detail=""):
     slack = max(hi - lo, int(np.ceil(0.05 * hi)))
     note_tol(label, abs(iters - 0.5 * (lo + hi)), 0.5 * (hi - lo) + slack, "%s: device %d, oracle band %d..%d" % (detail, iters, lo, hi))
     assert lo - slack <= iters <= hi + slack, (label, detail, iters, band)
+
+
+def closed_form_cases():
+    """projected_cg instances whose answer follows by hand from src/basic_tralcnlss.jl:702-761 — dyadic data, so every product and sum
+    on the way is exact in fp64 and the expected step holds to the last bit whatever the summation order (case `diag` excepted: its
+    alpha = 2/5).  They pin the oracle and the device to the reference's text independently of each other.
+    Yields dicts: J, C, mu, A, fix, g, wl, wu, kappa2 and the expected w, status (0 solved, 1 bound_hit, 2 negative_curvature, 4 none),
+    iters (the reference's `iter` at exit, starts at 1) and n_hmul, plus `rtol` for w."""
+    g4 = np.array([1.0, -2.0, 0.5, 4.0])
+    wide = 100.0 * np.ones(4)
+    Z4 = np.zeros((0, 4))
+    I4 = np.eye(4)
+    nofix = np.zeros(4, dtype=bool)
+    # H = I: v = g, p = -g, p'Hp = r'v = 21.25, alpha = 1 < gamma = 100/4; w = -g, r = 0: solved after one product (:733-748)
+    yield dict(name="identity", J=I4, C=Z4, mu=1.0, A=Z4, fix=nofix, g=g4, wl=-wide, wu=wide, kappa2=0.1,
+               w=-g4, status=0, iters=2, n_hmul=1, rtol=0.0)
+    # the same with |w_i| <= 1/2: gamma = min(.5/1, .5/2, .5/.5, .5/4) = 1/8 < alpha = 1: w = p/8, bound_hit, iter stays 1 (:735-737)
+    yield dict(name="bound_hit", J=I4, C=Z4, mu=1.0, A=Z4, fix=nofix, g=g4, wl=-0.5 * np.ones(4), wu=0.5 * np.ones(4), kappa2=0.1,
+               w=-g4 / 8.0, status=1, iters=1, n_hmul=1, rtol=0.0)
+    # H = 0: p'Hp = 0 <= atol and |p'Hp| <= atol: no step at all (:725-727), negative_curvature with w = 0
+    yield dict(name="zero_curvature", J=np.zeros((1, 4)), C=Z4, mu=1.0, A=Z4, fix=nofix, g=g4, wl=-wide, wu=wide, kappa2=0.1,
+               w=np.zeros(4), status=2, iters=1, n_hmul=1, rtol=0.0)
+    # H = mu C'C with mu = -1, C = I: p'Hp = -21.25 < -atol: the step to the boundary of :727-729, w = p/8
+    yield dict(name="negative_curvature_step", J=np.zeros((1, 4)), C=I4, mu=-1.0, A=Z4, fix=nofix, g=g4, wl=-0.5 * np.ones(4),
+               wu=0.5 * np.ones(4), kappa2=0.1, w=-g4 / 8.0, status=2, iters=1, n_hmul=1, rtol=0.0)
+    # H = 4 I through the C block (J = 0, C = I, mu = 4): alpha = 1/4, w = -g/4
+    yield dict(name="penalty_block", J=np.zeros((1, 4)), C=I4, mu=4.0, A=Z4, fix=nofix, g=g4, wl=-wide, wu=wide, kappa2=0.1,
+               w=-g4 / 4.0, status=0, iters=2, n_hmul=1, rtol=0.0)
+    # one equality sum(w) = 0, H = I: v = g - mean(g) = g - 7/8 (A A' = 4, all dyadic), alpha = 1, w = -v, then P(r) = P(7/8 * 1) = 0
+    yield dict(name="equality_mean", J=I4, C=Z4, mu=1.0, A=np.ones((1, 4)), fix=nofix, g=g4, wl=-wide, wu=wide, kappa2=0.1,
+               w=-(g4 - 0.875), status=0, iters=2, n_hmul=1, rtol=4e-16)
+    # a fixed variable (w_l = w_u = 0 there): v = mask(g), w = -mask(g); max_iter = 2 (4 - 0 - 1)
+    fix1 = np.array([False, True, False, False])
+    yield dict(name="fixed_variable", J=I4, C=Z4, mu=1.0, A=Z4, fix=fix1, g=g4, wl=np.where(fix1, 0.0, -wide), wu=np.where(fix1, 0.0, wide),
+               kappa2=0.1, w=np.where(fix1, 0.0, -g4), status=0, iters=2, n_hmul=1, rtol=0.0)
+    # everything fixed: max_iter = 0, the loop is never entered, iter = 1 != max_iter: status none (:759-761), w = 0
+    fixall = np.ones(2, dtype=bool)
+    yield dict(name="all_fixed", J=np.eye(2), C=np.zeros((0, 2)), mu=1.0, A=np.zeros((0, 2)), fix=fixall, g=np.array([1.0, -2.0]),
+               wl=np.zeros(2), wu=np.zeros(2), kappa2=0.1, w=np.zeros(2), status=4, iters=1, n_hmul=0, rtol=0.0)
+    # H = diag(1, 4), g = (1, 1), tight tolerance: CG is exact after two products, w = -(1, 1/4) (alpha_1 = 2/5 is not dyadic: 4 ulps)
+    yield dict(name="diag", J=np.diag([1.0, 2.0]), C=np.zeros((0, 2)), mu=1.0, A=np.zeros((0, 2)), fix=np.zeros(2, dtype=bool),
+               g=np.ones(2), wl=-100.0 * np.ones(2), wu=100.0 * np.ones(2), kappa2=1e-12, w=np.array([-1.0, -0.25]), status=0, iters=3,
+               n_hmul=2, rtol=1e-15)
+
+
+def closed_form_cauchy_cases():
+    """cauchy_step instances solved by hand from src/basic_tralcnlss.jl:574-639 (H = I in two variables, x = 0, bounds +-1, dyadic data:
+    every phi', phi'' and breakpoint is exact).  Yields g, delta and the expected step, active set and number of H*d products."""
+    # d = (4, 1/2): phi' = -16.25, phi'' = 16.25, dt = 1 > theta = 1/4 (variable 0 reaches its bound): s = (1, 1/8), d = (0, 1/2);
+    # then phi' = -1/4 + 1/16, phi'' = 1/4, dt = 3/4 < theta = 7/4: the minimiser lies inside the second segment, s = (1, 1/2)
+    yield dict(name="interior_minimum_on_second_segment", g=np.array([-4.0, -0.5]), delta=100.0, s=np.array([1.0, 0.5]), fix=np.array([True, False]), n_hmul=2)
+    # trust region 1/2: theta = 1/8, s = (1/2, 1/16); then dt = 7/8 EQUALS theta = 7/8 — `dt < theta` (:622) is false, the search
+    # advances to the breakpoint and fixes variable 1 too; with n - mA variables fixed the loop ends (:615) after a third product
+    yield dict(name="tie_between_minimiser_and_breakpoint", g=np.array([-4.0, -0.5]), delta=0.5, s=np.array([0.5, 0.5]), fix=np.array([True, True]), n_hmul=3)
+    # g = 0: phi' = 0 >= 0 at once (:620)
+    yield dict(name="stationary_point", g=np.zeros(2), delta=1.0, s=np.zeros(2), fix=np.array([False, False]), n_hmul=1)
+    # d = (4, 1): theta = 1/4, then dt = 3/4 = theta again: both variables end on their bounds
+    yield dict(name="corner", g=np.array([-4.0, -1.0]), delta=100.0, s=np.ones(2), fix=np.array([True, True]), n_hmul=3)

@@ -253,3 +253,54 @@ def test_cauchy_search_is_multimodal_on_the_pinned_operands():
         assert len(keys) >= 2, "the oracle is unimodal on these operands: the discrepancy would be the device's"
         assert far >= 1e-2
         assert len(red_sets - set(keys)) >= 1
+
+
+def test_oracles_against_answers_derived_by_hand():
+    """Both CPU restatements against projected_cg instances solved by hand from the reference's text (tests/_util.py::closed_form_cases:
+    dyadic data, every intermediate exact): the oracle is pinned to src/basic_tralcnlss.jl:702-761 on these, not to itself."""
+    import benlsip_oracle as BO
+    from _util import closed_form_cases
+    n_cases = 0
+    for c in closed_form_cases():
+        n = c["g"].shape[0]
+        L = R.chol_lower(c["A"] @ c["A"].T)
+        cons = R.make_mixed_constraints(c["A"], L, c["fix"] if c["fix"].any() else None, l=-1e3 * np.ones(n), u=1e3 * np.ones(n))
+        tr = R.CGTrace()
+        w, st, it = R.projected_cg(c["g"], R.AlHessian(c["J"], c["C"], c["mu"]), c["wl"], c["wu"], cons, c["kappa2"], trace=tr)
+        assert (int(st), it, tr.n_hmul) == (c["status"], c["iters"], c["n_hmul"]), (c["name"], int(st), it, tr.n_hmul)
+        assert np.max(np.abs(w - c["w"])) <= c["rtol"] * np.max(np.abs(c["w"])) if c["rtol"] else np.array_equal(w, c["w"]), (c["name"], w, c["w"])
+        w2, st2, it2, nh2, _ = BO.projected_cg(c["g"], c["J"], c["C"], c["mu"], c["wl"], c["wu"], c["A"], c["fix"], cons.chol_L, c["kappa2"])
+        assert (int(st2), it2, nh2) == (c["status"], c["iters"], c["n_hmul"]), (c["name"], "C port", int(st2), it2, nh2)
+        assert np.max(np.abs(w2 - c["w"])) <= c["rtol"] * np.max(np.abs(c["w"])) if c["rtol"] else np.array_equal(w2, c["w"]), (c["name"], "C port", w2)
+        n_cases += 1
+    assert n_cases == 9
+
+
+def test_oracle_cauchy_step_against_answers_derived_by_hand():
+    """The NumPy restatement of cauchy_step on the instances of tests/_util.py::closed_form_cauchy_cases (exact arithmetic, incl. an exact tie
+    between the segment's minimiser and the next breakpoint): pinned to src/basic_tralcnlss.jl:574-639 by hand, not to itself."""
+    from _util import closed_form_cauchy_cases
+    Z = np.zeros((0, 2))
+    L0 = R.chol_lower(Z @ Z.T)
+    for c in closed_form_cauchy_cases():
+        cons = R.make_mixed_constraints(Z, L0, l=-np.ones(2), u=np.ones(2))
+        count = [0]
+
+        class Ops(R.NumpyOps):
+            def hmul(self, H, v):
+                count[0] += 1
+                return R.hmul(H, v)
+        s = R.cauchy_step(np.zeros(2), c["g"], R.AlHessian(np.eye(2), Z, 1.0), L0, cons, c["delta"], Ops())
+        assert np.array_equal(s, c["s"]) and np.array_equal(cons.fixvars, c["fix"]) and count[0] == c["n_hmul"], (c["name"], s, cons.fixvars, count[0])
+
+
+def test_oracle_minor_iterate_against_an_answer_derived_by_hand():
+    """minor_iterate (:649-675) with H = I: projected_cg returns w = -mask(g) (closed_form_cases `fixed_variable`), the line search has
+    w'Hw = |w|^2 = -g'w, so alpha_opt = 1 exactly, no bound on a free variable (:662-665): the minor step is -mask(g) to the last bit."""
+    g = np.array([1.0, -2.0, 0.5, 4.0])
+    fix = np.array([False, True, False, False])
+    x = np.array([0.0, 1.0, 0.0, 0.0])
+    Z = np.zeros((0, 4))
+    cons = R.make_mixed_constraints(Z, R.chol_lower(Z @ Z.T), fix, l=-np.ones(4), u=np.ones(4))
+    w, st = R.minor_iterate(x, np.zeros(4), g, R.AlHessian(np.eye(4), Z, 1.0), cons, 100.0, 0.1)
+    assert int(st) == 0 and np.array_equal(w, np.where(fix, 0.0, -g))

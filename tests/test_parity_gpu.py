@@ -386,6 +386,68 @@ def test_pcg_golden_fixtures(bh, cg_fused):
         cons.close()
 
 
+@pytest.mark.parametrize("image", [1, 0], ids=["row_space", "sweeping"])
+def test_cauchy_step_answers_derived_by_hand(bh, image):
+    """bh_cauchy_step on the instances solved by hand from src/basic_tralcnlss.jl:574-639 (tests/_util.py::closed_form_cauchy_cases): step to
+    the last bit, active set, number of passes — also at the exact tie between a segment's minimiser and the next breakpoint — in the
+    row-space form and in the one that sweeps J per breakpoint."""
+    from _util import closed_form_cauchy_cases
+    bh.set_option("cauchy_image", image)
+    try:
+        H = bh.AlHessian(np.eye(2), None, 1.0)
+        for c in closed_form_cauchy_cases():
+            cons = bh.MixedConstraints(np.zeros((0, 2)), None, None, l=-np.ones(2), u=np.ones(2))
+            s, info = bh.cauchy_step(np.zeros(2), c["g"], H, cons, c["delta"], full_output=True)
+            assert np.array_equal(s, c["s"]) and np.array_equal(np.asarray(cons.fixvars, dtype=bool), c["fix"]) and info["n_hmul"] == c["n_hmul"], \
+                (c["name"], image, s, cons.fixvars, info)
+            cons.close()
+        H.close()
+    finally:
+        bh.set_option("cauchy_image", 1)
+
+
+def test_minor_iterate_answer_derived_by_hand(bh, cg_fused):
+    """bh_minor_iterate with H = I and one variable on its bound: w = -mask(g) from the CG loop, alpha_opt = -g'w / w'Hw = 1 exactly, no
+    bound on a free variable (:662-665) — the minor step is -mask(g) to the last bit (the same derivation pins the oracle on the CPU)."""
+    g = np.array([1.0, -2.0, 0.5, 4.0])
+    fix = np.array([False, True, False, False])
+    x = np.array([0.0, 1.0, 0.0, 0.0])
+    H = bh.AlHessian(np.eye(4), None, 1.0)
+    cons = bh.MixedConstraints(np.zeros((0, 4)), None, fix, l=-np.ones(4), u=np.ones(4))
+    w, st, info = bh.minor_iterate(x, np.zeros(4), g, H, cons, 100.0, 0.1, full_output=True)
+    assert int(st) == 0 and info["alpha"] == 1.0 and np.array_equal(w, np.where(fix, 0.0, -g)), (int(st), info, w)
+    H.close()
+    cons.close()
+
+
+def test_pcg_answers_derived_by_hand(bh, cg_fused):
+    """projected_cg through the C ABI on the instances solved by hand from the reference's text (tests/_util.py::closed_form_cases: H = I,
+    a bound hit, zero and negative curvature, the penalty block alone, one equality, a fixed variable, everything fixed, a two-step
+    diagonal): exit status, `iter`, product count and — the data are dyadic — the step to the last bit, in every iteration shape and
+    both projection forms.  The same cases pin the two CPU oracles (tests/test_oracle_cpu.py)."""
+    from _util import closed_form_cases
+    for form in (1, 0):
+        bh.set_option("proj_form", form)
+        try:
+            for c in closed_form_cases():
+                H = bh.AlHessian(c["J"], c["C"], c["mu"])
+                L = R.chol_lower(c["A"] @ c["A"].T) if form == 0 else None
+                if form == 0:
+                    n = c["g"].shape[0]
+                    L = R.make_mixed_constraints(c["A"], L, c["fix"] if c["fix"].any() else None, l=-np.ones(n), u=np.ones(n)).chol_L
+                cons = bh.MixedConstraints(c["A"], L, c["fix"])
+                w, st, info = bh.projected_cg(c["g"], H, c["wl"], c["wu"], cons, c["kappa2"], full_output=True)
+                assert (int(st), info["iters"], info["n_hmul"]) == (c["status"], c["iters"], c["n_hmul"]), (c["name"], form, int(st), info)
+                if c["rtol"]:
+                    assert np.max(np.abs(w - c["w"])) <= c["rtol"] * np.max(np.abs(c["w"])), (c["name"], form, w, c["w"])
+                else:
+                    assert np.array_equal(w, c["w"]), (c["name"], form, w, c["w"])
+                H.close()
+                cons.close()
+        finally:
+            bh.set_option("proj_form", 1)
+
+
 @pytest.mark.parametrize("d,n,q,mA,nfix,seed", [(50, 20, 0, 0, 4, 1), (200, 64, 1, 3, 10, 2), (300, 100, 0, 0, 0, 3), (512, 257, 0, 2, 30, 4),
                                                 (1024, 512, 0, 0, 64, 5), (2000, 1000, 2, 8, 100, 6), (600, 300, 0, 16, 0, 7)])
 def test_pcg_random_instances(bh, cg_fused, d, n, q, mA, nfix, seed):
