@@ -3087,7 +3087,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                 hipLaunchKernelGGL(cauchy_image_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)ia.part, img_grid, img_scal, (const CgState*)c.d_state);
                 BH_TRY(allreduce_inplace(img_scal, 2, H, c.d_state));
             }
-            hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CG_T), 0, s, a);
+            hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CA_T), 0, s, a);
             BH_HIP(hipGetLastError());
             return BH_OK;
         }
@@ -3115,7 +3115,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         }
         if (mA > 0) BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));       // d = P(-g)   :592 / :632  (box: kept in place)
         BH_TRY(launch_hmul(H, c.p, c.Hp, c.d_state, -1));           // Hd = H*d    :609 / :633
-        hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CG_T), 0, s, a);
+        hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CA_T), 0, s, a);
         BH_HIP(hipGetLastError());
         return BH_OK;
     };

@@ -17,6 +17,8 @@ namespace bh {
 //   status = index fixed at the last breakpoint (-1: none), approx_solved = min_found, neg_curvature = 1 when no
 //   breakpoint exists (the reference would index fixvars[-1]), pad = breakpoints taken, n_hmul = H*d products.
 // ------------------------------------------------------------------------------------------
+constexpr int CA_T = 512;        // threads of cauchy_advance_kernel
+
 struct CauchyArgs {
     CgState* st;
     const double* x; const double* g; const double* xlow; const double* xupp;
@@ -198,15 +200,21 @@ __global__ __launch_bounds__(64) void cauchy_image_sum_kernel(const double* __re
 
 __global__ __launch_bounds__(256) void cauchy_image_kernel(CauchyImgArgs a) {
     const CgState* st = a.st;
-    if (st->done) return;
     __shared__ double scratch[2 * 4];
+    // (the first row's t_d, t_s are asked for together with the loop state — the column entry of J needs `ind` and follows; at
+    // config 3 a thread owns one row, so the pass is two dependent memory round trips instead of three)
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t ic = min(i0, a.nrows - 1 > 0 ? a.nrows - 1 : (int64_t)0);
+    const double td0 = a.td[ic], ts0 = a.ts[ic];
+    const int done_in = st->done;
     const int ind = st->status;                 // the variable fixed at the previous breakpoint, its step and its old d component
     const double theta = st->gamma, dind = st->beta;
+    if (done_in) return;
     double acc[2] = {0.0, 0.0};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256) {
-        double td = a.td[i], ts = 0.0;
+    for (int64_t i = i0; i < a.nrows; i += (int64_t)gridDim.x * 256) {
+        double td = (i == i0) ? td0 : a.td[i], ts = 0.0;
         if (!a.first) {
-            ts = __dadd_rn(a.ts[i], __dmul_rn(theta, td));                       // s_c += theta d          (:628)
+            ts = __dadd_rn((i == i0) ? ts0 : a.ts[i], __dmul_rn(theta, td));    // s_c += theta d          (:628)
             td = __dsub_rn(td, __dmul_rn(dind, a.J[i * a.ld + ind]));            // d[ind] = 0              (:632, box)
             a.td[i] = td;
         }
@@ -219,11 +227,12 @@ __global__ __launch_bounds__(256) void cauchy_image_kernel(CauchyImgArgs a) {
     if (threadIdx.x == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
 }
 
-__device__ __forceinline__ void publish_cauchy(const CauchyArgs& a, const CgState* st) {
+// progress word of the search: tag | error flag | done | breakpoints taken | passes run
+__device__ __forceinline__ void publish_cauchy_word(const CauchyArgs& a, int err, int done, int breakpoints, int passes) {
     if (a.mirror == nullptr) return;
-    const unsigned long long wv = ((unsigned long long)(a.tag & 0xffffu) << 48) | ((unsigned long long)(st->neg_curvature & 0xf) << 44) |
-                                  ((unsigned long long)(st->done & 0xf) << 40) | ((unsigned long long)(st->pad & 0xfffff) << 20) |
-                                  (unsigned long long)(st->n_hmul & 0xfffff);
+    const unsigned long long wv = ((unsigned long long)(a.tag & 0xffffu) << 48) | ((unsigned long long)(err & 0xf) << 44) |
+                                  ((unsigned long long)(done & 0xf) << 40) | ((unsigned long long)(breakpoints & 0xfffff) << 20) |
+                                  (unsigned long long)(passes & 0xfffff);
     __hip_atomic_store(a.mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -255,43 +264,56 @@ __global__ __launch_bounds__(CG_T) void cauchy_init_kernel(CauchyArgs a) {
 
 // One pass: phi_p, phi_pp for the current (d, Hd) (:610-611 / :634-635), the while test (:615), next_breakpoint (:617),
 // the three-way branch (:620-636) including s_c update and the active-set growth of add_active! (poly:240-249).
-__global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
-    constexpr int NW = CG_T / 64;
-    __shared__ double scratch[2 * NW];
+// Latency-bound (one workgroup of CA_T = 512 threads: eight waves leave each 256 VGPRs, so the 56 operands of a thread stay in registers —
+// the 1024-thread shape of the CG step kernels spilled here, and a kernel that touches scratch pays for it at every dispatch): every load of the pass — the loop state, the row-space partial sums, the
+// first batch of vector elements — is issued before anything is used (also before the `done` gate: the addresses are valid either
+// way), and the three sums and the arg-min share one barrier.
+__global__ __launch_bounds__(CA_T) void cauchy_advance_kernel(CauchyArgs a) {
+    constexpr int NW = CA_T / 64;
+    __shared__ double scratch[4 * NW];
     __shared__ int iscratch[NW];
     CgState* st = a.st;
-    if (st->done) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double INF = __longlong_as_double(0x7ff0000000000000ll);
-    double sums[2] = {0.0, 0.0};
-    double gd[1] = {0.0};
+    const bool img = a.img_part != nullptr;      // s'Hd and d'Hd come from the row-space partial sums: Hd is not read
+    // ---- loads first ---------------------------------------------------------------------------------------------------------
+    const int done_in = st->done;
+    const int nfix = st->iter;
+    const int n_hmul_in = st->n_hmul, pad_in = st->pad;          // (read here, not at the tail: thread 0's last stores wait for nothing)
+    LaneBatch<8> b0, b1;
+    if (img) { b0.issue(a.img_part, a.img_G); b1.issue(a.img_part + a.img_G, a.img_G); }
+    // Eight elements per thread and batch (all of them for n <= 4096): their seven operands are requested together and the pass
+    // runs from registers, one memory round trip instead of eight; the first batch's d and s are kept for the update below.
+    constexpr int E = 8;
+    double dv[E], hv[E], sv[E], gv[E], lv[E], uv[E];
+    int fv[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = min(tid + k * CA_T, a.n - 1);
+        dv[k] = a.d[i]; hv[k] = img ? 0.0 : a.Hd[i]; sv[k] = a.s[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixrank[i];
+    }
+    if (done_in) return;
+    double x3[3] = {0.0, 0.0, 0.0};              // s'Hd, d'Hd, g'd
     double th = INF;
     int ind = 0x7fffffff;
-    // Four elements per thread and batch (all of them for n <= 4096): their seven operands are requested together and the pass
-    // runs from registers in the same element order as a plain strided loop (same bits), one memory round trip instead of four;
-    // the first batch's d and s are kept for the update below.
-    constexpr int E = 4;
     double d0[E], s0[E];
-    const bool img = a.img_part != nullptr;      // s'Hd and d'Hd come from the row-space partial sums: Hd is not read
-    double img_sums[2] = {0.0, 0.0};
-    if (img) { img_sums[0] = wave_fixed_sum(a.img_part, a.img_G); img_sums[1] = wave_fixed_sum(a.img_part + a.img_G, a.img_G); }
-    for (int base = 0; base < a.n; base += E * CG_T) {
-        double dv[E], hv[E], sv[E], gv[E], lv[E], uv[E];
-        int fv[E];
+    for (int base = 0; base < a.n; base += E * CA_T) {
+        if (base > 0) {
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const int i = min(base + tid + k * CG_T, a.n - 1);
-            dv[k] = a.d[i]; hv[k] = img ? 0.0 : a.Hd[i]; sv[k] = a.s[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixrank[i];
+            for (int k = 0; k < E; ++k) {
+                const int i = min(base + tid + k * CA_T, a.n - 1);
+                dv[k] = a.d[i]; hv[k] = img ? 0.0 : a.Hd[i]; sv[k] = a.s[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixrank[i];
+            }
         }
 #pragma unroll
         for (int k = 0; k < E; ++k) {
-            const int i = base + tid + k * CG_T;
+            const int i = base + tid + k * CA_T;
             if (base == 0) { d0[k] = dv[k]; s0[k] = sv[k]; }
             if (i >= a.n) continue;
             const double di = dv[k], hdi = hv[k], si = sv[k];
-            sums[0] = fma(si, hdi, sums[0]);
-            sums[1] = fma(di, hdi, sums[1]);
-            gd[0] = fma(gv[k], di, gd[0]);
+            x3[0] = fma(si, hdi, x3[0]);
+            x3[1] = fma(di, hdi, x3[1]);
+            x3[2] = fma(gv[k], di, x3[2]);
             if (fv[k] < 0) {                                          // :547
                 double t = INF;
                 if (di < 0.0) t = __ddiv_rn(__dsub_rn(lv[k], si), di);       // :549
@@ -300,30 +322,34 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
             }
         }
     }
-    block_reduce<CG_T, 2>(sums, scratch, OpSum(), 0.0);
-    block_reduce<CG_T, 1>(gd, scratch, OpSum(), 0.0);
-    if (img) { sums[0] = img_sums[0]; sums[1] = img_sums[1]; }
-    // arg-min with the smallest index among equal thetas
+    // ---- the three sums (block_reduce's order: wave butterfly, then the waves in ascending order) and the arg-min with the
+    //      smallest index among equal thetas, behind one pair of barriers
+#pragma unroll
+    for (int q = 0; q < 3; ++q) x3[q] = wave_reduce(x3[q], OpSum());
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const double t2 = __shfl_xor(th, off);
         const int i2 = __shfl_xor(ind, off);
         if (t2 < th || (t2 == th && i2 < ind)) { th = t2; ind = i2; }
     }
+    if (lane == 0) {
+        scratch[wave] = x3[0]; scratch[NW + wave] = x3[1]; scratch[2 * NW + wave] = x3[2];
+        scratch[3 * NW + wave] = th; iscratch[wave] = ind;
+    }
     __syncthreads();
-    if (lane == 0) { scratch[wave] = th; iscratch[wave] = ind; }
-    __syncthreads();
-    th = scratch[0]; ind = iscratch[0];
+    double sums[2] = {0.0, 0.0}, gd = 0.0;
+    for (int w = 0; w < NW; ++w) { sums[0] += scratch[w]; sums[1] += scratch[NW + w]; gd += scratch[2 * NW + w]; }
+    th = scratch[3 * NW]; ind = iscratch[0];
     for (int w = 1; w < NW; ++w) {
-        const double t2 = scratch[w];
+        const double t2 = scratch[3 * NW + w];
         const int i2 = iscratch[w];
         if (t2 < th || (t2 == th && i2 < ind)) { th = t2; ind = i2; }
     }
+    if (img) { sums[0] = wave_sum(b0.fold_sum(a.img_part, a.img_G)); sums[1] = wave_sum(b1.fold_sum(a.img_part + a.img_G, a.img_G)); }
     if (ind == 0x7fffffff) ind = -1;                              // :544
 
-    const double phi_p = __dadd_rn(sums[0], gd[0]);               // :610 / :634
+    const double phi_p = __dadd_rn(sums[0], gd);                  // :610 / :634
     const double phi_pp = sums[1];                                // :611 / :635
-    const int nfix = st->iter;
     int done = 0, min_found = 0, err = 0, advance = 0;
     double step = 0.0;
     const double delta_t = (phi_pp > 0.0) ? __ddiv_rn(-phi_p, phi_pp) : 0.0;     // :618
@@ -340,14 +366,14 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
     if (step != 0.0 || advance) {
 #pragma unroll
         for (int k = 0; k < E; ++k) {                                 // the first batch: from registers
-            const int i = tid + k * CG_T;
+            const int i = tid + k * CA_T;
             if (i >= a.n) continue;
             a.s[i] = __dadd_rn(s0[k], __dmul_rn(step, d0[k]));
             // box constraints: projection!(lincons, -g, d) after add_active!(ind) only zeroes d[ind] (:632) — done by the
             // thread that owns the element, after it has used the old value (kept in st->beta for the image-space update)
             if (advance && a.box && i == ind) { st->beta = d0[k]; a.d[i] = 0.0; }
         }
-        for (int i = E * CG_T + tid; i < a.n; i += CG_T) {
+        for (int i = E * CA_T + tid; i < a.n; i += CA_T) {
             const double di = a.d[i];
             a.s[i] = __dadd_rn(a.s[i], __dmul_rn(step, di));
             if (advance && a.box && i == ind) { st->beta = di; a.d[i] = 0.0; }
@@ -355,14 +381,14 @@ __global__ __launch_bounds__(CG_T) void cauchy_advance_kernel(CauchyArgs a) {
     }
     if (tid == 0) {
         st->rtv = phi_p; st->pHp = phi_pp; st->gamma = th; st->alpha = delta_t;
-        st->n_hmul += 1;
+        st->n_hmul = n_hmul_in + 1;
         st->approx_solved = min_found; st->neg_curvature = err;
         if (advance) {
             a.fixrank[ind] = 0;                                   // add_active!: fixvars[ind] = true (poly:246)
-            st->iter = nfix + 1; st->status = ind; st->pad += 1;
+            st->iter = nfix + 1; st->status = ind; st->pad = pad_in + 1;
         }
         st->done = done; st->need_proj = done ? 0 : 1;
-        publish_cauchy(a, st);
+        publish_cauchy_word(a, err, done, pad_in + (advance ? 1 : 0), n_hmul_in + 1);
     }
 }
 
