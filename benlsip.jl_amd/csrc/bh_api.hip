@@ -109,6 +109,7 @@ struct Ctx {
     // one J v sweep at the start, then no sweep over J per breakpoint), 0 = one H*d sweep per breakpoint as the reference does
     int64_t opt_cauchy_image = 1;
     int64_t opt_cauchy_image_max_ma = 64;   // ... and with up to this many linear equalities (0..64)
+    int64_t opt_cauchy_fused = 1;           // box constraints, one rank, row-space form: ONE kernel per breakpoint (cauchy_fused_kernel)
     int64_t opt_cauchy_gemm = 1;            // B = J D A' of that form in one sweep on the matrix cores (0: mA J v sweeps over masked rows of A)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
@@ -371,6 +372,7 @@ int grid_for(int cfg, int64_t nrows) {
 }
 
 constexpr int kEvCap = 512;
+constexpr int kCauchyFusedGrid = 256;    // workgroups of cauchy_fused_kernel (512 rows each per sweep); its partial sums are 2 x [2][256]
 constexpr int kCauchyImgGrid = 512;      // workgroups of cauchy_image_kernel (256 rows each per sweep of the row space)
 
 }  // namespace
@@ -1363,6 +1365,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "gram_mfma")) { g_ctx.opt_gram_mfma = value; return BH_OK; }
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image")) { g_ctx.opt_cauchy_image = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cauchy_fused")) { g_ctx.opt_cauchy_fused = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_gemm")) { g_ctx.opt_cauchy_gemm = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image_max_ma")) { g_ctx.opt_cauchy_image_max_ma = std::min<int64_t>(std::max<int64_t>(0, value), 64); return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
@@ -3018,8 +3021,11 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     const bool image = g_ctx.opt_cauchy_image != 0 &&
                        (mA == 0 || mA <= g_ctx.opt_cauchy_image_max_ma || (mA <= 64 && P->last_cauchy_passes > 4 * (1 + mA)));
     const bool image_gen = image && mA > 0;
+    // ... and there ONE kernel per breakpoint: the decision of pass k-1 in the prologue of the row kernel of pass k (cauchy_fused_kernel)
+    const bool fused = image && !image_gen && !comm_active() && g_ctx.opt_cauchy_fused != 0;
     const int64_t img_rows = H->d + H->q_eff;
-    const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 255) / 256));
+    const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(fused ? kCauchyFusedGrid : kCauchyImgGrid, (img_rows + 255) / 256));
+    const int fused_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyFusedGrid, (img_rows + CA_T - 1) / CA_T));
     const int64_t img_cap = (std::max<int64_t>(H->d + H->q, 1) + 1) / 2 * 2;              // rows, rounded up to even (16-byte aligned tails)
     double* img_scal = nullptr;
     if (image) {
@@ -3036,12 +3042,42 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         }
     }
 
+    CauchyPass* pp = nullptr;
+    double* part_pp[2] = {nullptr, nullptr};
+    double* sbuf[2] = {c.w, c.Hp};                                     // s_c ping-pong of the fused form (H*d is never formed there)
+    if (fused) {
+        pp = reinterpret_cast<CauchyPass*>(img_scal + 8);             // 2 x 32 bytes in the 16-double tail of timg
+        part_pp[0] = H->timg + 2 * img_cap; part_pp[1] = part_pp[0] + 2 * kCauchyFusedGrid;
+        a.fixpass = reinterpret_cast<int*>(c.v); a.pp0 = pp;
+    }
     P->active_set = false;             // device mask is authoritative until adopt_mask below
     hipLaunchKernelGGL(cauchy_init_kernel, dim3(1), dim3(CG_T), 0, s, a);
     if (mA > 0) BH_TRY(launch_reduced_factor(P, true, nullptr));
     const int max_pass = (int)(n + 1);
     int launched = 0;
     auto launch_pass = [&](int index) -> int32_t {
+        if (fused && index > 0) {
+            CauchyFusedArgs fa{};
+            fa.pp = pp; fa.k = index; fa.g = a.g; fa.dl = a.dl; fa.du = a.du; fa.sbuf[0] = sbuf[0]; fa.sbuf[1] = sbuf[1];
+            fa.fixpass = a.fixpass; fa.fixrank = P->fixrank; fa.n = (int)n; fa.nmm = a.nmm;
+            fa.J = H->Jd; fa.ld = H->ld; fa.nrows = img_rows; fa.d_rows = H->d; fa.mu = H->mu;
+            fa.td = H->timg; fa.ts = H->timg + img_cap;
+            fa.part_in = part_pp[(index - 1) & 1]; fa.Gin = index == 1 ? img_grid : fused_grid; fa.part_out = part_pp[index & 1];
+            fa.mirror = a.mirror; fa.tag = a.tag;
+            hipLaunchKernelGGL(cauchy_fused_kernel, dim3(fused_grid), dim3(CA_T), 0, s, fa);
+            BH_HIP(hipGetLastError());
+            return BH_OK;
+        }
+        if (fused) {                                                   // launch 0: t_d = J~ d_0 (:609 in the row space), t_s = 0, their sums
+            CauchyImgArgs ia{};
+            ia.st = c.d_state; ia.J = H->Jd; ia.ld = H->ld; ia.nrows = img_rows; ia.d_rows = H->d; ia.mu = H->mu;
+            ia.td = H->timg; ia.ts = H->timg + img_cap; ia.part = part_pp[0]; ia.first = 1;
+            BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));
+            H->stats.n_jv += 1;
+            hipLaunchKernelGGL(cauchy_image_kernel, dim3(img_grid), dim3(256), 0, s, ia);
+            BH_HIP(hipGetLastError());
+            return BH_OK;
+        }
         if (image) {
             const int64_t rows_cap = img_cap;
             CauchyImgArgs ia{};
@@ -3122,8 +3158,11 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     MirrorWord mw{};
     // image-space passes take ~17 us: keep a deeper queue ahead of the GPU (over RCCL every over-launched pass costs a collective)
     const int batch = !image ? launch_batch_size(H) : (comm_active() && !use_peer_path()) ? 4 : 8;
+    // (fused form: launch k carries decision k-1, so `launched` launches stand for launched - 1 passes)
+    const int off = fused ? 1 : 0;
+    const int max_launch = max_pass + off;
     auto launch_batch = [&](int nb) -> int32_t {
-        nb = std::min(nb, max_pass - launched);
+        nb = std::min(nb, max_launch - launched);
         for (int i = 0; i < nb; ++i) BH_TRY(launch_pass(launched + i));
         launched += nb;
         return BH_OK;
@@ -3131,16 +3170,17 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     // Same launch-ahead schedule and the same rank-independent exit predicate as pcg_run (mirror: status field = error
     // flag, iter field = breakpoints, n_hmul = passes run).
     auto done_by = [&](int target) { return mw.done && mw.n_hmul <= target; };
-    BH_TRY(launch_batch(2));
+    BH_TRY(launch_batch(2 + off));
     while (true) {
-        const int target = launched;
-        const bool more = launched < max_pass;
+        const int target = launched - off;
+        const bool more = launched < max_launch;
         if (more) BH_TRY(launch_batch(batch));
         BH_TRY(wait_mirror(c, a.tag, target, &mw));
         if (done_by(target) || !more) break;
     }
-    BH_TRY(wait_mirror(c, a.tag, launched, &mw));
-    BH_TRY(fetch_vec(s_out, c.w, n, dev));
+    BH_TRY(wait_mirror(c, a.tag, launched - off, &mw));
+    // (fused form: decision j is taken by launch j+1, which writes s_c into buffer (j+1) & 1)
+    BH_TRY(fetch_vec(s_out, fused ? sbuf[mw.n_hmul & 1] : c.w, n, dev));
     int info_host = 0;
     BH_TRY(adopt_device_mask(P, fix_chunks_out, &info_host));     // drains the stream; canonical fixrank / fixidx, P->nfix
     if (!image) H->stats.n_hmul += mw.n_hmul;                  // (image-space search: passes, not sweeps over J)

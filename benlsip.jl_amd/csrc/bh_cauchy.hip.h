@@ -17,7 +17,11 @@ namespace bh {
 //   status = index fixed at the last breakpoint (-1: none), approx_solved = min_found, neg_curvature = 1 when no
 //   breakpoint exists (the reference would index fixvars[-1]), pad = breakpoints taken, n_hmul = H*d products.
 // ------------------------------------------------------------------------------------------
-constexpr int CA_T = 512;        // threads of cauchy_advance_kernel
+constexpr int CA_T = 512;        // threads of cauchy_advance_kernel / cauchy_fused_kernel
+
+// Loop state of the one-kernel-per-breakpoint form (cauchy_fused_kernel): two records, launch k reads [(k + 1) & 1] and workgroup 0
+// writes [k & 1] — no workgroup reads a word its own launch writes.
+struct CauchyPass { int done, nfix, n_hmul, breakpoints, err, pad0, pad1, pad2; };
 
 struct CauchyArgs {
     CgState* st;
@@ -30,6 +34,8 @@ struct CauchyArgs {
     unsigned long long* mirror; unsigned tag;
     // image-space search (box constraints): s'Hd and d'Hd arrive as per-workgroup partial sums over the rows of J (cauchy_image_kernel)
     const double* img_part; int img_G;
+    // one-kernel-per-breakpoint form: "fixed before launch k" marks and the first loop-state record (NULL: not used)
+    int* fixpass; CauchyPass* pp0;
 };
 
 // Image-space form of the box-constrained search.  With box constraints a breakpoint only zeroes one component of d, so in the
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(CG_T) void cauchy_init_kernel(CauchyArgs a) {
         const double xi = a.x[i];
         const bool act = (__dsub_rn(xi, a.xlow[i]) <= a.atol) || (__dsub_rn(a.xupp[i], xi) <= a.atol);   // poly:211
         a.fixrank[i] = act ? 0 : -1;
+        if (a.fixpass != nullptr) a.fixpass[i] = act ? -1 : 0x7fffffff;
         cnt[0] += act ? 1.0 : 0.0;
         a.negg[i] = -a.g[i];
         if (a.box) a.d[i] = act ? 0.0 : -a.g[i];                // d = projection(lincons, -g) for box constraints (:592)
@@ -259,6 +266,7 @@ __global__ __launch_bounds__(CG_T) void cauchy_init_kernel(CauchyArgs a) {
         st->iter = (int)cnt[0]; st->max_iter = a.nmm;
         st->approx_solved = 0; st->outside_region = 0; st->neg_curvature = 0;
         st->done = 0; st->status = -1; st->n_hmul = 0; st->need_proj = 1; st->pad = 0;
+        if (a.pp0 != nullptr) { CauchyPass z{}; z.nfix = (int)cnt[0]; *a.pp0 = z; }
     }
 }
 
@@ -390,6 +398,167 @@ __global__ __launch_bounds__(CA_T) void cauchy_advance_kernel(CauchyArgs a) {
         st->done = done; st->need_proj = done ? 0 : 1;
         publish_cauchy_word(a, err, done, pad_in + (advance ? 1 : 0), n_hmul_in + 1);
     }
+}
+
+// ONE kernel per breakpoint (box constraints, one rank, row-space form).  The two-kernel pass above is
+//     cauchy_image_kernel (rows: apply the last breakpoint, leave partial sums)  ->  cauchy_advance_kernel (one workgroup: decide)
+// and each kernel boundary costs more than the work behind it.  Here the decision moves into the prologue of the row kernel:
+// launch k >= 1 has EVERY workgroup redo decision k-1 for the whole vector (same operands, same order, same bits: 144 KiB from L2),
+// then apply it to its own rows and leave the partial sums for launch k+1.  Nothing a launch writes is read by the same launch:
+//   s            ping-pong (read [(k+1)&1], write [k&1]; the 64-element group i>>6 is stored by workgroup (i>>6) mod G);
+//   d            not stored at all: with box constraints d_i = -g_i while i is free, 0 afterwards (:592, :632);
+//   fixed flags  fixpass[i] = launch that fixed i (-1: active from the start, INT_MAX: free); launch k treats i as fixed iff
+//                fixpass[i] < k, so the mark workgroup 0 sets in launch k (value k) reads as "free" in launch k either way;
+//   loop state   two CauchyPass records; a gated launch copies the record forward so that `done` survives over-launching;
+//   partial sums ping-pong.
+// Launch 0 is cauchy_image_kernel(first = 1): the sums of t_d = J~ d_0 only.  Decisions = launches - 1.
+struct CauchyFusedArgs {
+    CauchyPass* pp; int k;
+    const double* g; const double* dl; const double* du;
+    double* sbuf[2];
+    int* fixpass; int* fixrank;
+    int n, nmm;
+    const double* J; int64_t ld; int64_t nrows, d_rows; double mu;
+    double* td; double* ts;
+    const double* part_in; int Gin;          // [2][Gin] from the previous launch
+    double* part_out;                        // [2][gridDim.x]
+    unsigned long long* mirror; unsigned tag;
+};
+
+__global__ __launch_bounds__(CA_T) void cauchy_fused_kernel(CauchyFusedArgs a) {
+    constexpr int NW = CA_T / 64;
+    constexpr int E = 8;
+    __shared__ double scratch[3 * NW];
+    __shared__ int iscratch[NW];
+    __shared__ double rscratch[2 * NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double INF = __longlong_as_double(0x7ff0000000000000ll);
+    const CauchyPass* in = a.pp + ((a.k + 1) & 1);
+    CauchyPass* out = a.pp + (a.k & 1);
+    const double* __restrict__ s_in = a.sbuf[(a.k + 1) & 1];
+    double* __restrict__ s_out = a.sbuf[a.k & 1];
+    // ---- every load that does not depend on the decision goes out first ----------------------------------------------------------
+    const int done_in = in->done, nfix = in->nfix, nh_in = in->n_hmul, bp_in = in->breakpoints, err_in = in->err;
+    LaneBatch<8> b0, b1;
+    b0.issue(a.part_in, a.Gin); b1.issue(a.part_in + a.Gin, a.Gin);
+    const int64_t r0 = (int64_t)blockIdx.x * CA_T + tid;
+    const int64_t rc = min(r0, a.nrows > 0 ? a.nrows - 1 : (int64_t)0);
+    const double td0 = a.td[rc], ts0 = a.ts[rc];
+    double sv[E], gv[E], lv[E], uv[E];
+    int fv[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = min(tid + k * CA_T, a.n - 1);
+        sv[k] = s_in[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixpass[i];
+    }
+    if (done_in) {                                   // over-launched: hand the final record on, touch nothing else
+        if (blockIdx.x == 0 && tid == 0) { CauchyPass z = *in; *out = z; }
+        return;
+    }
+    // ---- decision k-1, by every workgroup (cauchy_advance_kernel's arithmetic, element for element) ---------------------------
+    double gd = 0.0, th = INF, dbest = 0.0;
+    int ind = 0x7fffffff;
+    double s0[E], d0[E];
+    for (int base = 0; base < a.n; base += E * CA_T) {
+        if (base > 0) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const int i = min(base + tid + k * CA_T, a.n - 1);
+                sv[k] = s_in[i]; gv[k] = a.g[i]; lv[k] = a.dl[i]; uv[k] = a.du[i]; fv[k] = a.fixpass[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const int i = base + tid + k * CA_T;
+            const bool fixed = fv[k] < a.k;
+            const double di = fixed ? 0.0 : -gv[k];                   // d = projection(lincons, -g), box constraints (:592 / :632)
+            if (base == 0) { s0[k] = sv[k]; d0[k] = di; }
+            if (i >= a.n) continue;
+            const double si = sv[k];
+            gd = fma(gv[k], di, gd);
+            if (!fixed) {                                             // :547
+                double t = INF;
+                if (di < 0.0) t = __ddiv_rn(__dsub_rn(lv[k], si), di);       // :549
+                else if (di > 0.0) t = __ddiv_rn(__dsub_rn(uv[k], si), di);  // :551
+                if (t < th) { th = t; ind = i; dbest = di; }          // strict <: first minimiser in index order (:555)
+            }
+        }
+    }
+    gd = wave_reduce(gd, OpSum());
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double t2 = __shfl_xor(th, off), d2 = __shfl_xor(dbest, off);
+        const int i2 = __shfl_xor(ind, off);
+        if (t2 < th || (t2 == th && i2 < ind)) { th = t2; ind = i2; dbest = d2; }
+    }
+    if (lane == 0) { scratch[wave] = gd; scratch[NW + wave] = th; scratch[2 * NW + wave] = dbest; iscratch[wave] = ind; }
+    __syncthreads();
+    gd = 0.0;
+    for (int w = 0; w < NW; ++w) gd += scratch[w];
+    th = scratch[NW]; dbest = scratch[2 * NW]; ind = iscratch[0];
+    for (int w = 1; w < NW; ++w) {
+        const double t2 = scratch[NW + w];
+        const int i2 = iscratch[w];
+        if (t2 < th || (t2 == th && i2 < ind)) { th = t2; ind = i2; dbest = scratch[2 * NW + w]; }
+    }
+    const double shd = wave_sum(b0.fold_sum(a.part_in, a.Gin)), dhd = wave_sum(b1.fold_sum(a.part_in + a.Gin, a.Gin));
+    if (ind == 0x7fffffff) ind = -1;                              // :544
+    const double phi_p = __dadd_rn(shd, gd);                      // :610 / :634
+    const double phi_pp = dhd;                                    // :611 / :635
+    int done = 0, err = 0, advance = 0;
+    double step = 0.0;
+    const double delta_t = (phi_pp > 0.0) ? __ddiv_rn(-phi_p, phi_pp) : 0.0;     // :618
+    if (!(nfix < a.nmm)) {                                        // :615
+        done = 1;
+    } else if (phi_p >= 0.0) {                                    // :620
+        done = 1;
+    } else if (phi_p < 0.0 && phi_pp > 0.0 && delta_t < th) {     // :622
+        step = delta_t; done = 1;                                 // :625
+    } else {                                                      // :627
+        if (ind < 0) { err = 1; done = 1; }
+        else { step = th; advance = 1; }                          // :628
+    }
+    // ---- s_c += step d (:625 / :628): the groups of 64 elements this workgroup owns ----------------------------------------------
+    const bool move = (step != 0.0 || advance);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int i = tid + k * CA_T;
+        if (i < a.n && ((i >> 6) % (int)gridDim.x) == (int)blockIdx.x)
+            s_out[i] = move ? __dadd_rn(s0[k], __dmul_rn(step, d0[k])) : s0[k];
+    }
+    for (int i = E * CA_T + tid; i < a.n; i += CA_T) {
+        if (((i >> 6) % (int)gridDim.x) != (int)blockIdx.x) continue;
+        const double di = (a.fixpass[i] < a.k) ? 0.0 : -a.g[i];
+        const double si = s_in[i];
+        s_out[i] = move ? __dadd_rn(si, __dmul_rn(step, di)) : si;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        CauchyPass z{};
+        z.done = done; z.nfix = nfix + advance; z.n_hmul = nh_in + 1; z.breakpoints = bp_in + advance; z.err = err_in | err;
+        *out = z;
+        if (advance) { a.fixpass[ind] = a.k; a.fixrank[ind] = 0; }    // add_active!: fixvars[ind] = true (poly:246)
+        if (a.mirror != nullptr) {
+            const unsigned long long wv = ((unsigned long long)(a.tag & 0xffffu) << 48) | ((unsigned long long)(z.err & 0xf) << 44) |
+                                          ((unsigned long long)(done & 0xf) << 40) | ((unsigned long long)(z.breakpoints & 0xfffff) << 20) |
+                                          (unsigned long long)(z.n_hmul & 0xfffff);
+            __hip_atomic_store(a.mirror, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (done) return;
+    // ---- this workgroup's rows: t_s += theta t_d, t_d -= d_ind J~[:, ind], and the partial sums for the next decision -------------
+    double acc[2] = {0.0, 0.0};
+    for (int64_t i = r0; i < a.nrows; i += (int64_t)gridDim.x * CA_T) {
+        double td = (i == r0) ? td0 : a.td[i];
+        const double ts = __dadd_rn((i == r0) ? ts0 : a.ts[i], __dmul_rn(step, td));   // s_c += theta d     (:628)
+        td = __dsub_rn(td, __dmul_rn(dbest, a.J[i * a.ld + ind]));                   // d[ind] = 0         (:632, box)
+        a.td[i] = td;
+        a.ts[i] = ts;
+        const double w = (i < a.d_rows) ? 1.0 : a.mu;
+        acc[0] = fma(w * ts, td, acc[0]);
+        acc[1] = fma(w * td, td, acc[1]);
+    }
+    block_reduce<CA_T, 2>(acc, rscratch, OpSum(), 0.0);
+    if (tid == 0) { a.part_out[blockIdx.x] = acc[0]; a.part_out[gridDim.x + blockIdx.x] = acc[1]; }
 }
 
 // M <- M - a a',  a = column `ind` of A (the variable that just became fixed):  A_free A_free' after add_active!.

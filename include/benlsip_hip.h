@@ -353,6 +353,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *                        B = J D A' (rows x mA) next to J d, J s_c — two sweeps over J up front (a: J v; B: "cauchy_gemm"), one
  *                        column of J per breakpoint afterwards; above this value and up to 64 rows the form is used when the
  *                        previous search on the same bh_proj took more than 4 (1 + mA) passes
+ *   "cauchy_fused"   [1] that search (box constraints, one rank) with ONE kernel per breakpoint: every workgroup of the row kernel redoes the
+ *                        previous pass's decision in its prologue (s_c and the loop state are ping-pong buffers); 0: two kernels per pass
  *   "cauchy_gemm"    [1] B = J D A' in ONE sweep over J on the fp64 matrix cores (a tall-skinny GEMM: M = rows of J, N = mA, K = n);
  *                        0: mA J v sweeps over the masked rows of A
  *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)

@@ -386,13 +386,14 @@ def test_pcg_golden_fixtures(bh, cg_fused):
         cons.close()
 
 
-@pytest.mark.parametrize("image", [1, 0], ids=["row_space", "sweeping"])
-def test_cauchy_step_answers_derived_by_hand(bh, image):
+@pytest.mark.parametrize("image,fused", [(1, 1), (1, 0), (0, 0)], ids=["row_space_one_kernel_per_breakpoint", "row_space_two_kernels", "sweeping"])
+def test_cauchy_step_answers_derived_by_hand(bh, image, fused):
     """bh_cauchy_step on the instances solved by hand from src/basic_tralcnlss.jl:574-639 (tests/_util.py::closed_form_cauchy_cases): step to
     the last bit, active set, number of passes — also at the exact tie between a segment's minimiser and the next breakpoint — in the
-    row-space form and in the one that sweeps J per breakpoint."""
+    row-space forms (one kernel per breakpoint, two) and in the one that sweeps J per breakpoint."""
     from _util import closed_form_cauchy_cases
     bh.set_option("cauchy_image", image)
+    bh.set_option("cauchy_fused", fused)
     try:
         H = bh.AlHessian(np.eye(2), None, 1.0)
         for c in closed_form_cauchy_cases():
@@ -404,6 +405,7 @@ def test_cauchy_step_answers_derived_by_hand(bh, image):
         H.close()
     finally:
         bh.set_option("cauchy_image", 1)
+        bh.set_option("cauchy_fused", 1)
 
 
 def test_minor_iterate_answer_derived_by_hand(bh, cg_fused):
@@ -1006,8 +1008,9 @@ def test_cauchy_step_in_the_row_space_of_j(bh, capsys, d, n, q, nact, delta_scal
     s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, Ops())
     H = bh.AlHessian(J, C, 2.5)
     out = {}
-    for mode in (1, 0):
-        bh.set_option("cauchy_image", mode)
+    for mode in (2, 1, 0):             # 2: row space, one kernel per breakpoint (default); 1: row space, two kernels; 0: one H*d sweep per breakpoint
+        bh.set_option("cauchy_image", 1 if mode else 0)
+        bh.set_option("cauchy_fused", 1 if mode == 2 else 0)
         try:
             cons = bh.MixedConstraints(Z, None, l=xlow, u=xupp)
             n0 = H.stats()["n_hmul"]
@@ -1015,16 +1018,17 @@ def test_cauchy_step_in_the_row_space_of_j(bh, capsys, d, n, q, nact, delta_scal
             swept = H.stats()["n_hmul"] - n0
         finally:
             bh.set_option("cauchy_image", 1)
+            bh.set_option("cauchy_fused", 1)
         assert np.array_equal(cons.fixvars, cons_o.fixvars), (mode, np.flatnonzero(cons.fixvars), np.flatnonzero(cons_o.fixvars))
-        assert info["n_hmul"] == calls[0]                                   # passes = the oracle's H*d products
-        assert swept == (0 if mode == 1 else calls[0]), (mode, swept, calls[0])
+        assert info["n_hmul"] == calls[0], (mode, info, calls[0])           # passes = the oracle's H*d products
+        assert swept == (0 if mode else calls[0]), (mode, swept, calls[0])
         rel = relnorm(s, s_ref)
-        note_tol("cauchy_step (box): step vs oracle, 1e-9", rel, 1e-9, "cauchy_image=%d d=%d n=%d q=%d, %d breakpoints" % (mode, d, n, q, info["n_breakpoints"]))
+        note_tol("cauchy_step (box): step vs oracle, 1e-9", rel, 1e-9, "form=%d d=%d n=%d q=%d, %d breakpoints" % (mode, d, n, q, info["n_breakpoints"]))
         assert rel <= 1e-9, (mode, rel)
         assert np.all(x + s <= xupp + 1e-12) and np.all(x + s >= xlow - 1e-12) and np.max(np.abs(s)) <= delta * (1 + 1e-12)
         out[mode] = s
         cons.close()
-    assert relnorm(out[1], out[0]) <= 1e-9
+    assert relnorm(out[1], out[0]) <= 1e-9 and relnorm(out[2], out[0]) <= 1e-9
     H.close()
 
 
