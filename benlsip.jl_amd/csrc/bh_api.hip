@@ -3026,6 +3026,10 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     const int64_t img_rows = H->d + H->q_eff;
     const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(fused ? kCauchyFusedGrid : kCauchyImgGrid, (img_rows + 255) / 256));
     const int fused_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyFusedGrid, (img_rows + CA_T - 1) / CA_T));
+    // with equalities a workgroup takes tiles of 64 rows; the partial sums still have to fit the [2][kCauchyImgGrid] slot
+    const int gen_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 63) / 64));
+    const bool gen_tiled = mA > 16;                                   // (few equalities: one row per thread, see bh_cauchy.hip.h)
+    const int part_G = (image_gen && gen_tiled) ? gen_grid : img_grid;   // how many partial sums a row kernel leaves
     const int64_t img_cap = (std::max<int64_t>(H->d + H->q, 1) + 1) / 2 * 2;              // rows, rounded up to even (16-byte aligned tails)
     double* img_scal = nullptr;
     if (image) {
@@ -3033,7 +3037,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
         if (!H->timg) BH_TRY(dev_alloc(&H->timg, 2 * img_cap + 2 * kCauchyImgGrid + 16));
         img_scal = H->timg + 2 * img_cap + 2 * kCauchyImgGrid;
         a.img_part = comm_active() ? img_scal : H->timg + 2 * img_cap;
-        a.img_G = comm_active() ? 1 : img_grid;
+        a.img_G = comm_active() ? 1 : part_G;
         if (image_gen && H->timg_gen_doubles < (int64_t)(1 + mA) * img_cap) {
             dev_free(H->timg_gen);
             H->timg_gen = nullptr; H->timg_gen_doubles = 0;
@@ -3085,12 +3089,23 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
             ia.td = H->timg; ia.ts = H->timg + rows_cap; ia.part = H->timg + 2 * rows_cap; ia.first = index == 0 ? 1 : 0;
             if (image_gen) {
                 // factor of the current active set and y = (A_free A_free')^{-1} A_free(-g) (left in P->tw), as in the sweeping form
-                if (index > 0) {
-                    hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
+                if (index > 0 && mA <= 64) {
+                    // Gram downdate + refactorisation and t = A_free(-g) in ONE launch (independent jobs), then the solves and d = P(-g)
+                    P->linv_valid = false;
+                    ProjArgs pa = proj_args(P, c.d_state, true, true);
+                    hipLaunchKernelGGL(cauchy_factor_leftmul_kernel, dim3(1 + mA), dim3(256), 0, s, P->M, P->Lr, mA, P->info, pa, (const double*)c.r,
                                        (const CgState*)c.d_state);
-                    BH_TRY(launch_chol(P, (const CgState*)c.d_state));
+                    hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
+                    hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 4>), dim3(((int)(n + 1) / 2 + 63) / 64), dim3(256), 0, s, pa, (const double*)c.r, c.p);
+                    BH_HIP(hipGetLastError());
+                } else {
+                    if (index > 0) {
+                        hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
+                                           (const CgState*)c.d_state);
+                        BH_TRY(launch_chol(P, (const CgState*)c.d_state));
+                    }
+                    BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));           // d = P(-g) for the advance kernel's g.d and s update
                 }
-                BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));               // d = P(-g) for the advance kernel's g.d and s update
                 if (index == 0) {
                     // a = J~ D g: one J v sweep over the masked g.  B = J~ D A' (rows x mA): ONE sweep on the matrix cores
                     // (image_b_mfma_kernel) when the images share their leading dimension, else mA J v sweeps over masked rows of A
@@ -3111,7 +3126,8 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                 CauchyImgGenArgs ga{};
                 ga.b = ia; ga.a = H->timg_gen; ga.B = H->timg_gen + rows_cap; ga.rows_cap = rows_cap; ga.mA = mA;
                 ga.A = P->Ad; ga.ldA = P->ldA; ga.tw = P->tw; ga.g = a.g;
-                hipLaunchKernelGGL(cauchy_image_gen_kernel, dim3(img_grid), dim3(256), 0, s, ga);
+                if (gen_tiled) hipLaunchKernelGGL(cauchy_image_gen_kernel, dim3(gen_grid), dim3(256), 0, s, ga);
+                else hipLaunchKernelGGL(cauchy_image_gen_rows_kernel, dim3(img_grid), dim3(256), 0, s, ga);
             } else {
                 if (index == 0) {
                     BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));              // t_d = J~ d_0 (:609 in the row space)
@@ -3120,7 +3136,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                 hipLaunchKernelGGL(cauchy_image_kernel, dim3(img_grid), dim3(256), 0, s, ia);
             }
             if (comm_active()) {
-                hipLaunchKernelGGL(cauchy_image_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)ia.part, img_grid, img_scal, (const CgState*)c.d_state);
+                hipLaunchKernelGGL(cauchy_image_sum_kernel, dim3(1), dim3(64), 0, s, (const double*)ia.part, part_G, img_scal, (const CgState*)c.d_state);
                 BH_TRY(allreduce_inplace(img_scal, 2, H, c.d_state));
             }
             hipLaunchKernelGGL(cauchy_advance_kernel, dim3(1), dim3(CA_T), 0, s, a);

@@ -68,7 +68,9 @@ struct CauchyImgGenArgs {
     const double* g;
 };
 
-__global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs ga) {
+// Few equalities (mA <= 16): one row per thread, the columns of B in a serial loop — 8.2 us per pass at mA = 8 against 10.3 us for the
+// tiled form below, whose barriers and idle waves cost more than its loads in flight gain there.
+__global__ __launch_bounds__(256) void cauchy_image_gen_rows_kernel(CauchyImgGenArgs ga) {
     const CauchyImgArgs& a = ga.b;
     const CgState* st = a.st;
     if (st->done) return;
@@ -104,6 +106,77 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs 
     }
     block_reduce<256, 2>(acc, scratch, OpSum(), 0.0);
     if (threadIdx.x == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+}
+
+// A workgroup works on tiles of 64 rows: wave w owns columns [w cpw, (w+1) cpw) of B (cpw = ceil(mA / 4) <= 16) for all 64 rows, so
+// up to 16 independent 512-byte loads per wave are in flight (one row per thread and a serial loop over mA columns left the
+// 67 MB this pass moves at mA = 64 at 2.5 TB/s); the column entry of J — the expensive strided load — is fetched once per row by
+// wave 0 and shared through LDS, the four partial dot products meet there too.  Fixed order of accumulation: bit-reproducible.
+__global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs ga) {
+    const CauchyImgArgs& a = ga.b;
+    const CgState* st = a.st;
+    if (st->done) return;
+    __shared__ double s_acol[64], s_y[64], s_col[64], s_dot[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ind = st->status;
+    const double theta = st->gamma;
+    const bool upd = !a.first && ind >= 0;
+    if ((int)threadIdx.x < ga.mA) {
+        s_acol[threadIdx.x] = upd ? ga.A[(int64_t)threadIdx.x * ga.ldA + ind] : 0.0;
+        s_y[threadIdx.x] = ga.tw[threadIdx.x];
+    }
+    const double g_ind = upd ? ga.g[ind] : 0.0;
+    const int cpw = (ga.mA + 3) >> 2, j0 = wave * cpw;
+    double acc[2] = {0.0, 0.0};
+    for (int64_t tile = blockIdx.x; tile * 64 < a.nrows; tile += gridDim.x) {
+        const int64_t i = tile * 64 + lane;
+        const bool vrow = i < a.nrows;
+        const int64_t ic = vrow ? i : a.nrows - 1;
+        // this wave's entries of B for the tile: all loads out before any is used
+        double b[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int jj = min(j0 + k, ga.mA - 1);
+            b[k] = (k < cpw) ? ga.B[(int64_t)jj * ga.rows_cap + ic] : 0.0;       // (k < cpw is uniform over the launch)
+        }
+        double ai = 0.0, ts = 0.0;
+        if (wave == 0) {
+            ai = ga.a[ic];
+            if (!a.first) ts = __dadd_rn(a.ts[ic], __dmul_rn(theta, a.td[ic]));  // s_c += theta d  with the PREVIOUS d   (:628)
+            const double col = upd ? a.J[ic * a.ld + ind] : 0.0;
+            s_col[lane] = col;
+            if (upd) { ai = __dsub_rn(ai, __dmul_rn(g_ind, col)); if (vrow) ga.a[i] = ai; }
+        }
+        __syncthreads();                                              // s_col (and, first tile, s_acol / s_y) are in place
+        const double col = s_col[lane];
+        double dot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int jj = j0 + k;
+            if (k < cpw && jj < ga.mA) {
+                double bij = b[k];
+                if (upd) { bij = __dsub_rn(bij, __dmul_rn(col, s_acol[jj])); if (vrow) ga.B[(int64_t)jj * ga.rows_cap + i] = bij; }
+                dot = fma(bij, s_y[jj], dot);
+            }
+        }
+        s_dot[wave][lane] = dot;
+        __syncthreads();
+        if (wave == 0 && vrow) {
+            double td = -ai;                                          // t_d = -a - B y
+            td = __dsub_rn(td, s_dot[0][lane]); td = __dsub_rn(td, s_dot[1][lane]);
+            td = __dsub_rn(td, s_dot[2][lane]); td = __dsub_rn(td, s_dot[3][lane]);
+            a.td[i] = td;
+            a.ts[i] = ts;
+            const double w = (i < a.d_rows) ? 1.0 : a.mu;
+            acc[0] = fma(w * ts, td, acc[0]);
+            acc[1] = fma(w * td, td, acc[1]);
+        }
+        __syncthreads();                                              // wave 0 is done with s_dot before the next tile overwrites it
+    }
+    if (wave == 0) {
+        acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]);
+        if (lane == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+    }
 }
 
 // B = J~ D A'  (rows x mA, column j at B + j * rows_cap) on the matrix cores: the one place on this path where a tile of J meets a

@@ -79,11 +79,10 @@ __device__ __forceinline__ double left_mul_row(const double2* __restrict__ rp, c
 // left_mul: tw[0:mA] = A x (one workgroup per row: 4 waves share the row, fixed-order combine), and in the augmented
 // form tw[mA+k] = x[fixidx[k]] (:86-98).  Reduced form: the fixed components of x are masked out (A_free x_free).
 // grid = mA + ceil(nfix/256) blocks of 256 (gather blocks only in the augmented form).
-__global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const double* __restrict__ x) {
-    if (proj_skip(a.state)) return;
+__device__ __forceinline__ void proj_left_mul_body(const ProjArgs& a, const double* __restrict__ x, int block) {
     __shared__ double scratch[4];
-    if ((int)blockIdx.x < a.mA) {
-        const int row = blockIdx.x;
+    if (block < a.mA) {
+        const int row = block;
         const double2* rp = reinterpret_cast<const double2*>(a.A + (int64_t)row * a.ldA);
         const double2* x2 = reinterpret_cast<const double2*>(x);
         const int2* f2 = reinterpret_cast<const int2*>(a.fixrank);
@@ -94,9 +93,13 @@ __global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const do
         block_reduce<256, 1>(acc, scratch, OpSum(), 0.0);
         if (threadIdx.x == 0) a.tw[row] = acc[0];
     } else if (!a.reduced) {
-        const int k = ((int)blockIdx.x - a.mA) * 256 + threadIdx.x;
+        const int k = (block - a.mA) * 256 + threadIdx.x;
         if (k < a.nfix) a.tw[a.mA + k] = x[a.fixidx[k]];
     }
+}
+__global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const double* __restrict__ x) {
+    if (proj_skip(a.state)) return;
+    proj_left_mul_body(a, x, (int)blockIdx.x);
 }
 
 // out = r - left_mul_tr(tw)   (:72-84, :116, :134);  with SUBTRACT=false: out = left_mul_tr(tw).
@@ -332,23 +335,39 @@ __global__ __launch_bounds__(CG_T) void chol_lower_kernel(const double* __restri
 //   Strided form: src/dst are the top-left corners of an nb x nb (nb <= 64) block inside matrices with leading dimensions
 //   ld_src / ld_dst (in-place allowed); dinv_out receives the reciprocal diagonal; pivot failures are reported as
 //   info_base + column + 1.  reset_info: write 0 on success (stand-alone use) — blocked/in-loop callers only ever raise it.
-__global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int64_t ld_src, double* M, int64_t ld_dst, int m,
-                                                         double* dinv_out, int* info, int info_base, int reset_info,
-                                                         const CgState* gate) {
-    if (gate != nullptr && gate->done) return;
+// down_A != NULL: the Gram matrix is first downdated by column `down_ind` of A (the variable that has just become fixed:
+// A_free A_free' after add_active!, M <- M - a a' on the lower triangle, written back to Msrc) — gram_downdate_kernel's arithmetic,
+// without a launch of its own.
+__device__ __forceinline__ void chol_small_body(double* Msrc, int64_t ld_src, double* M, int64_t ld_dst, int m, double* dinv_out, int* info,
+                                                int info_base, int reset_info, const double* __restrict__ down_A, int64_t down_ldA,
+                                                int down_ind) {
     __shared__ __attribute__((aligned(16))) double colbuf[2][4][64];
+    __shared__ double s_down[64];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool down = down_A != nullptr && down_ind >= 0;
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int k = 16 * wave + c;
         a[c] = (lane < m && k < m && k <= lane) ? Msrc[lane + (int64_t)k * ld_src] : 0.0;
     }
+    if (down && wave == 0) s_down[lane] = (lane < m) ? down_A[(int64_t)lane * down_ldA + down_ind] : 0.0;
     if (tid == 0) s_bad = 0;
     double dinv_mine = 0.0;
     int buf = 0;
     __syncthreads();
+    if (down) {
+        const double ai = s_down[lane];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int k = 16 * wave + c;
+            if (lane < m && k < m && k <= lane) {
+                a[c] = fma(-ai, s_down[k], a[c]);
+                Msrc[lane + (int64_t)k * ld_src] = a[c];
+            }
+        }
+    }
     // FOUR columns per workgroup barrier: the wave that owns columns j0 .. j0+3 factors them one after the other — each column's
     // rank-one update goes into its own panel at once (wave-synchronous: no barrier inside a wave) — and publishes all four;
     // the waves to the right then apply the four updates in column order.  Every entry still receives its updates in
@@ -416,6 +435,21 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int
         if (s_bad != 0) info[0] = info_base + s_bad;
         else if (reset_info) info[0] = 0;
     }
+}
+__global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int64_t ld_src, double* M, int64_t ld_dst, int m,
+                                                         double* dinv_out, int* info, int info_base, int reset_info,
+                                                         const CgState* gate) {
+    if (gate != nullptr && gate->done) return;
+    chol_small_body(const_cast<double*>(Msrc), ld_src, M, ld_dst, m, dinv_out, info, info_base, reset_info, nullptr, 0, -1);
+}
+// One launch for the two independent small jobs of a Cauchy pass with linear equalities (mA <= 64, reduced form): workgroup 0
+// downdates the Gram matrix by the column of the variable fixed at the last breakpoint and refactors it (the reference rebuilds its
+// factor from scratch at every breakpoint too, :631), workgroups 1 .. mA form t = A_free (-g) row by row (left_mul, :86-98).
+__global__ __launch_bounds__(256) void cauchy_factor_leftmul_kernel(double* Mgram, double* L, int m, int* info, ProjArgs pa,
+                                                                   const double* __restrict__ x, const CgState* st) {
+    if (st->done) return;
+    if (blockIdx.x == 0) chol_small_body(Mgram, m, L, m, m, L + (int64_t)m * m, info, 0, 0, pa.A, pa.ldA, st->status);
+    else proj_left_mul_body(pa, x, (int)blockIdx.x - 1);
 }
 
 // ---- blocked Cholesky for m > 64: potrf (chol_small_kernel on the 64 x 64 diagonal block) / trsm / syrk per panel ------
