@@ -110,6 +110,7 @@ struct Ctx {
     int64_t opt_cauchy_image = 1;
     int64_t opt_cauchy_image_max_ma = 64;   // ... and with up to this many linear equalities (0..64)
     int64_t opt_cauchy_fused = 1;           // box constraints, one rank, row-space form: ONE kernel per breakpoint (cauchy_fused_kernel)
+    int64_t opt_cauchy_fused_grid = 0;      // experiment: workgroups of cauchy_fused_kernel (0: one row per thread up to kCauchyFusedGrid)
     int64_t opt_cauchy_gemm = 1;            // B = J D A' of that form in one sweep on the matrix cores (0: mA J v sweeps over masked rows of A)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
@@ -1366,6 +1367,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "chol_downdate")) { g_ctx.opt_chol_downdate = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image")) { g_ctx.opt_cauchy_image = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_fused")) { g_ctx.opt_cauchy_fused = value ? 1 : 0; return BH_OK; }
+    if (!strcmp(key, "cauchy_fused_grid")) { g_ctx.opt_cauchy_fused_grid = std::min<int64_t>(std::max<int64_t>(0, value), kCauchyFusedGrid); return BH_OK; }
     if (!strcmp(key, "cauchy_gemm")) { g_ctx.opt_cauchy_gemm = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image_max_ma")) { g_ctx.opt_cauchy_image_max_ma = std::min<int64_t>(std::max<int64_t>(0, value), 64); return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
@@ -3025,7 +3027,8 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
     const bool fused = image && !image_gen && !comm_active() && g_ctx.opt_cauchy_fused != 0;
     const int64_t img_rows = H->d + H->q_eff;
     const int img_grid = (int)std::max<int64_t>(1, std::min<int64_t>(fused ? kCauchyFusedGrid : kCauchyImgGrid, (img_rows + 255) / 256));
-    const int fused_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyFusedGrid, (img_rows + CA_T - 1) / CA_T));
+    const int fused_grid = g_ctx.opt_cauchy_fused_grid > 0 ? (int)g_ctx.opt_cauchy_fused_grid
+                                                           : (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyFusedGrid, (img_rows + CA_T - 1) / CA_T));
     // with equalities a workgroup takes tiles of 64 rows; the partial sums still have to fit the [2][kCauchyImgGrid] slot
     const int gen_grid = (int)std::max<int64_t>(1, std::min<int64_t>(kCauchyImgGrid, (img_rows + 63) / 64));
     const bool gen_tiled = mA > 16;                                   // (few equalities: one row per thread, see bh_cauchy.hip.h)
