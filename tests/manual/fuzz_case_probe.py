@@ -1,6 +1,6 @@
-"""Scratch: one case of tests/multirank/fuzz_cases.py on ONE rank, device vs oracle (python tools/scratch/fuzz_case_probe.py seed k)."""
+"""Scratch: one case of tests/multirank/fuzz_cases.py on ONE rank, device vs oracle (python tests/manual/fuzz_case_probe.py seed k)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/manual -> repo root
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "multirank")):
     sys.path.insert(0, p)
 import numpy as np
