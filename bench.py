@@ -329,8 +329,8 @@ def main():
             err = None
             try:
                 bh.init_distributed(rank, world, bcast)
-            except bh.BenlsipHipError as e:
-                err = str(e)
+            except Exception as e:                       # whatever went wrong here: the other ranks are waiting in the all-reduce below
+                err = "%s: %s" % (type(e).__name__, e)
             flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float64, device=pg_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.SUM)
             if flag.item() > 0:
