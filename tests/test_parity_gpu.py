@@ -1214,6 +1214,51 @@ def test_gram_on_matrix_cores_matches_valu_path(bh, mA, n, nfix):
     assert np.linalg.norm(out[1] - out[0]) <= tol * np.linalg.norm(r)
 
 
+def test_cauchy_search_forms_agree_at_config3_scale(bh, capsys):
+    """The Cauchy search at BASELINE config-3 scale (d = 65536, n = 4096: 128 workgroups of the fused kernel, 512 tiles of the
+    equality form — launch shapes the small parity cases never reach), where the oracle would take minutes: the device's own forms
+    against each other.  Box constraints: one kernel per breakpoint / two kernels / one H*d sweep per breakpoint (the reference's
+    arithmetic, src/basic_tralcnlss.jl:609,:633) must take the same breakpoints, end on the same active set and agree in the step to
+    1e-9; the step is feasible and reduces the model.  With 64 equalities: row-space form against the sweeping one."""
+    syn = bh.synthetic
+    d, n = 65536, 4096
+    H = bh.AlHessian.synthetic(d, n, seed=1, mu=10.0)
+    x, x_l, x_u, fix = syn.box_vectors(n, fix_every=8)
+    g = H.jtv(syn.residual_rows(0, d))
+    delta = syn.initial_tr(g)
+    Z = np.zeros((0, n))
+    A64 = syn.splitmix_uniform(4, np.arange(64 * n)).reshape((64, n), order="F")
+    for A, forms in ((Z, ((1, 1), (1, 0), (0, 0))), (A64, ((1, 0), (0, 0)))):
+        out = []
+        for image, fused in forms:
+            bh.set_option("cauchy_image", image)
+            bh.set_option("cauchy_fused", fused)
+            try:
+                cons = bh.MixedConstraints(A, None, None, l=x_l, u=x_u)
+                s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+            finally:
+                bh.set_option("cauchy_image", 1)
+                bh.set_option("cauchy_fused", 1)
+            out.append((s, np.asarray(cons.fixvars, dtype=bool).copy(), info["n_breakpoints"], info["n_hmul"]))
+            cons.close()
+        s0, f0, nb0, np0 = out[-1]                                    # the sweeping form
+        assert nb0 > 1000
+        for s, f, nb, npass in out[:-1]:
+            assert (nb, npass) == (nb0, np0) and np.array_equal(f, f0), (A.shape[0], nb, nb0, int((f != f0).sum()))
+            rel = relnorm(s, s0)
+            note_tol("cauchy_step at config-3 scale: row-space forms vs the sweeping form, 1e-9", rel, 1e-9, "mA=%d, %d breakpoints" % (A.shape[0], nb))
+            assert rel <= 1e-9, (A.shape[0], rel)
+        assert np.all(x + s0 <= x_u + 1e-12) and np.all(x + s0 >= x_l - 1e-12) and np.max(np.abs(s0)) <= delta * (1 + 1e-12)
+        if A.shape[0]:
+            assert np.linalg.norm(A @ s0) <= 1e-9 * np.linalg.norm(np.abs(A) @ np.abs(s0))
+        model = float(g @ s0 + 0.5 * (s0 @ (H * s0)))
+        assert model < 0.0
+        with capsys.disabled():
+            print("[Cauchy search at config-3 scale, mA = %d] %d breakpoints, %d active bounds, model reduction %.6e; forms agree to %.1e"
+                  % (A.shape[0], nb0, int(f0.sum()), model, max(relnorm(s, s0) for s, _, _, _ in out[:-1])))
+    H.close()
+
+
 def test_pcg_config3_full_size_against_oracle(bh):
     """BASELINE config 3 itself (d = 65536, n = 4096, box, p = 512; the bench.py workload): the device-generated J against the
     host generator (full 2 GiB image through J v and J' u) and projected_cg against the oracle at full size; then config 5
