@@ -3092,6 +3092,7 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
             ia.td = H->timg; ia.ts = H->timg + rows_cap; ia.part = H->timg + 2 * rows_cap; ia.first = index == 0 ? 1 : 0;
             if (image_gen) {
                 // factor of the current active set and y = (A_free A_free')^{-1} A_free(-g) (left in P->tw), as in the sweeping form
+                bool d_with_rows = false;
                 if (index > 0 && mA <= 64) {
                     // Gram downdate + refactorisation and t = A_free(-g) in ONE launch (independent jobs), then the solves and d = P(-g)
                     P->linv_valid = false;
@@ -3099,8 +3100,8 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                     hipLaunchKernelGGL(cauchy_factor_leftmul_kernel, dim3(1 + mA), dim3(256), 0, s, P->M, P->Lr, mA, P->info, pa, (const double*)c.r,
                                        (const CgState*)c.d_state);
                     hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
-                    hipLaunchKernelGGL((proj_left_mul_tr_kernel<true, 4>), dim3(((int)(n + 1) / 2 + 63) / 64), dim3(256), 0, s, pa, (const double*)c.r, c.p);
                     BH_HIP(hipGetLastError());
+                    d_with_rows = true;                                             // d = P(-g) shares the row kernel's launch below
                 } else {
                     if (index > 0) {
                         hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
@@ -3129,8 +3130,16 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                 CauchyImgGenArgs ga{};
                 ga.b = ia; ga.a = H->timg_gen; ga.B = H->timg_gen + rows_cap; ga.rows_cap = rows_cap; ga.mA = mA;
                 ga.A = P->Ad; ga.ldA = P->ldA; ga.tw = P->tw; ga.g = a.g;
-                if (gen_tiled) hipLaunchKernelGGL(cauchy_image_gen_kernel, dim3(gen_grid), dim3(256), 0, s, ga);
-                else hipLaunchKernelGGL(cauchy_image_gen_rows_kernel, dim3(img_grid), dim3(256), 0, s, ga);
+                if (d_with_rows) {
+                    ProjArgs pa = proj_args(P, c.d_state, true, true);
+                    const int dblocks = ((int)(n + 1) / 2 + 63) / 64;
+                    hipLaunchKernelGGL(cauchy_gen_rows_and_d_kernel, dim3(part_G + dblocks), dim3(256), 0, s, ga, gen_tiled ? 1 : 0, part_G, pa,
+                                       (const double*)c.r, c.p);
+                } else if (gen_tiled) {
+                    hipLaunchKernelGGL(cauchy_image_gen_kernel, dim3(gen_grid), dim3(256), 0, s, ga);
+                } else {
+                    hipLaunchKernelGGL(cauchy_image_gen_rows_kernel, dim3(img_grid), dim3(256), 0, s, ga);
+                }
             } else {
                 if (index == 0) {
                     BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));              // t_d = J~ d_0 (:609 in the row space)

@@ -70,10 +70,9 @@ struct CauchyImgGenArgs {
 
 // Few equalities (mA <= 16): one row per thread, the columns of B in a serial loop — 8.2 us per pass at mA = 8 against 10.3 us for the
 // tiled form below, whose barriers and idle waves cost more than its loads in flight gain there.
-__global__ __launch_bounds__(256) void cauchy_image_gen_rows_kernel(CauchyImgGenArgs ga) {
+__device__ __forceinline__ void cauchy_image_gen_rows_body(const CauchyImgGenArgs& ga, int block, int nblocks) {
     const CauchyImgArgs& a = ga.b;
     const CgState* st = a.st;
-    if (st->done) return;
     __shared__ double scratch[2 * 4];
     __shared__ double s_acol[64], s_y[64];
     const int ind = st->status;
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_rows_kernel(CauchyImgGen
     const double g_ind = upd ? ga.g[ind] : 0.0;
     __syncthreads();
     double acc[2] = {0.0, 0.0};
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.nrows; i += (int64_t)gridDim.x * 256) {
+    for (int64_t i = (int64_t)block * 256 + threadIdx.x; i < a.nrows; i += (int64_t)nblocks * 256) {
         double ts = 0.0;
         if (!a.first) ts = __dadd_rn(a.ts[i], __dmul_rn(theta, a.td[i]));        // s_c += theta d  with the PREVIOUS d   (:628)
         const double col = upd ? a.J[i * a.ld + ind] : 0.0;
@@ -105,17 +104,20 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_rows_kernel(CauchyImgGen
         acc[1] = fma(w * td, td, acc[1]);
     }
     block_reduce<256, 2>(acc, scratch, OpSum(), 0.0);
-    if (threadIdx.x == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+    if (threadIdx.x == 0) { a.part[block] = acc[0]; a.part[nblocks + block] = acc[1]; }
+}
+__global__ __launch_bounds__(256) void cauchy_image_gen_rows_kernel(CauchyImgGenArgs ga) {
+    if (ga.b.st->done) return;
+    cauchy_image_gen_rows_body(ga, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // A workgroup works on tiles of 64 rows: wave w owns columns [w cpw, (w+1) cpw) of B (cpw = ceil(mA / 4) <= 16) for all 64 rows, so
 // up to 16 independent 512-byte loads per wave are in flight (one row per thread and a serial loop over mA columns left the
 // 67 MB this pass moves at mA = 64 at 2.5 TB/s); the column entry of J — the expensive strided load — is fetched once per row by
 // wave 0 and shared through LDS, the four partial dot products meet there too.  Fixed order of accumulation: bit-reproducible.
-__global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs ga) {
+__device__ __forceinline__ void cauchy_image_gen_body(const CauchyImgGenArgs& ga, int block, int nblocks) {
     const CauchyImgArgs& a = ga.b;
     const CgState* st = a.st;
-    if (st->done) return;
     __shared__ double s_acol[64], s_y[64], s_col[64], s_dot[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ind = st->status;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs 
     const double g_ind = upd ? ga.g[ind] : 0.0;
     const int cpw = (ga.mA + 3) >> 2, j0 = wave * cpw;
     double acc[2] = {0.0, 0.0};
-    for (int64_t tile = blockIdx.x; tile * 64 < a.nrows; tile += gridDim.x) {
+    for (int64_t tile = block; tile * 64 < a.nrows; tile += nblocks) {
         const int64_t i = tile * 64 + lane;
         const bool vrow = i < a.nrows;
         const int64_t ic = vrow ? i : a.nrows - 1;
@@ -175,7 +177,23 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs 
     }
     if (wave == 0) {
         acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]);
-        if (lane == 0) { a.part[blockIdx.x] = acc[0]; a.part[gridDim.x + blockIdx.x] = acc[1]; }
+        if (lane == 0) { a.part[block] = acc[0]; a.part[nblocks + block] = acc[1]; }
+    }
+}
+__global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs ga) {
+    if (ga.b.st->done) return;
+    cauchy_image_gen_body(ga, (int)blockIdx.x, (int)gridDim.x);
+}
+// The row kernel and d = P(-g) = -g_free - A_free'y need the same y and nothing of each other: one launch, the first `row_blocks`
+// workgroups take the rows, the others 64 chunks of d each (proj_left_mul_tr_kernel<true, 4>'s arithmetic).
+__global__ __launch_bounds__(256) void cauchy_gen_rows_and_d_kernel(CauchyImgGenArgs ga, int tiled, int row_blocks, ProjArgs pa,
+                                                                   const double* __restrict__ r, double* __restrict__ d_out) {
+    if (ga.b.st->done) return;
+    if ((int)blockIdx.x < row_blocks) {
+        if (tiled) cauchy_image_gen_body(ga, (int)blockIdx.x, row_blocks);
+        else cauchy_image_gen_rows_body(ga, (int)blockIdx.x, row_blocks);
+    } else {
+        proj_left_mul_tr_body<true, 4>(pa, r, d_out, (int)blockIdx.x - row_blocks);
     }
 }
 

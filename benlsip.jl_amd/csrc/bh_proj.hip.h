@@ -107,12 +107,11 @@ __global__ __launch_bounds__(256) void proj_left_mul_kernel(ProjArgs a, const do
 // RG = 4 (256 threads) up to 64 rows, RG = 16 (1024 threads) above: the grid is only nch/64 workgroups, so many rows per
 // thread serialise (33.8 us at mA = 512 with RG = 4).
 template <bool SUBTRACT, int RG>
-__global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
-    if (proj_skip(a)) return;
+__device__ __forceinline__ void proj_left_mul_tr_body(const ProjArgs& a, const double* __restrict__ r, double* __restrict__ out, int block) {
     __shared__ double2 sm[RG][64];
     const int nch = (a.n + 1) >> 1;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    const int c = block * 64 + cl;
     double2 acc = make_double2(0.0, 0.0);
     if (c < nch) {
         const double2* A2 = reinterpret_cast<const double2*>(a.A);
@@ -163,7 +162,7 @@ __global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, c
             rv = fma(r1, v1, r0 * v0);
         }
         rv = wave_sum(rv);
-        if (cl == 0) a.rvpart[blockIdx.x] = rv;
+        if (cl == 0) a.rvpart[block] = rv;
         return;
     }
     if (c >= nch) return;
@@ -198,6 +197,11 @@ __global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, c
         out[j0] = acc.x;
         if (j1 < a.n) out[j1] = acc.y;
     }
+}
+template <bool SUBTRACT, int RG>
+__global__ __launch_bounds__(64 * RG) void proj_left_mul_tr_kernel(ProjArgs a, const double* __restrict__ r, double* __restrict__ out) {
+    if (proj_skip(a)) return;
+    proj_left_mul_tr_body<SUBTRACT, RG>(a, r, out, (int)blockIdx.x);
 }
 
 // Reduced-form factor, built on the device whenever the active set changes (bh_proj_set_active):
