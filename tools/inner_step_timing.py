@@ -25,16 +25,18 @@ def main():
     H = bh.AlHessian.synthetic(d, n, seed=1, mu=10.0)
     x, x_l, x_u, fix = syn.box_vectors(n, fix_every=8)
     g = H.jtv(syn.residual_rows(0, d))
+    mA = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # python tools/inner_step_timing.py 64: the config-5 shape
+    A = syn.splitmix_uniform(4, np.arange(mA * n)).reshape((mA, n), order="F") if mA else np.zeros((0, n))
     for dscale in (1.0, 0.1):
         delta = dscale * syn.initial_tr(g)
         for image in (1, 0, 1, 0):
             bh.set_option("cauchy_image", image)
-            cons = bh.MixedConstraints(np.zeros((0, n)), None, None, l=x_l, u=x_u)
+            cons = bh.MixedConstraints(A, None, None, l=x_l, u=x_u)
             t0 = time.perf_counter()
             s, mr, info = bh.inner_step(x, g, H, cons, delta, 50, 0.1, 0.1, full_output=True)
             el = time.perf_counter() - t0
-            print("delta = %.3g, cauchy_image = %d: %d Cauchy breakpoints, %d minor iterates, %d active bounds, model reduction %.6e: %.2f ms"
-                  % (delta, image, info["n_breakpoints"], len(info["minor"]), cons.nb_fix(), mr, 1e3 * el), flush=True)
+            print("mA = %d, delta = %.3g, cauchy_image = %d: %d Cauchy breakpoints, %d minor iterates, %d active bounds, model reduction %.6e: %.2f ms"
+                  % (mA, delta, image, info["n_breakpoints"], len(info["minor"]), cons.nb_fix(), mr, 1e3 * el), flush=True)
     bh.set_option("cauchy_image", 1)
 
 
