@@ -3092,24 +3092,18 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
             ia.td = H->timg; ia.ts = H->timg + rows_cap; ia.part = H->timg + 2 * rows_cap; ia.first = index == 0 ? 1 : 0;
             if (image_gen) {
                 // factor of the current active set and y = (A_free A_free')^{-1} A_free(-g) (left in P->tw), as in the sweeping form
-                bool d_with_rows = false;
-                if (index > 0 && mA <= 64) {
-                    // Gram downdate + refactorisation and t = A_free(-g) in ONE launch (independent jobs), then the solves and d = P(-g)
+                // Three launches per pass (image_gen implies mA <= 64): [downdate + refactorisation + right-hand side + the two solves: y]
+                // -> [rows | d = P(-g) | t_fresh = A_free(-g) for the next pass] -> [decision]
+                ProjArgs pa = proj_args(P, c.d_state, true, true);
+                if (index > 0) {
                     P->linv_valid = false;
-                    ProjArgs pa = proj_args(P, c.d_state, true, true);
-                    hipLaunchKernelGGL(cauchy_factor_leftmul_kernel, dim3(1 + mA), dim3(256), 0, s, P->M, P->Lr, mA, P->info, pa, (const double*)c.r,
-                                       (const CgState*)c.d_state);
-                    hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
-                    BH_HIP(hipGetLastError());
-                    d_with_rows = true;                                             // d = P(-g) shares the row kernel's launch below
+                    hipLaunchKernelGGL(cauchy_factor_solve_kernel, dim3(1), dim3(256), 0, s, P->M, P->Lr, mA, P->info, pa, (const double*)c.r,
+                                       (const double*)P->tpart, (const CgState*)c.d_state);
                 } else {
-                    if (index > 0) {
-                        hipLaunchKernelGGL(gram_downdate_kernel, dim3(std::max(1, (mA * mA + 255) / 256)), dim3(256), 0, s, P->M, P->Ad, P->ldA, mA,
-                                           (const CgState*)c.d_state);
-                        BH_TRY(launch_chol(P, (const CgState*)c.d_state));
-                    }
-                    BH_TRY(launch_project(P, c.r, c.p, c.d_state, true));           // d = P(-g) for the advance kernel's g.d and s update
+                    hipLaunchKernelGGL(proj_left_mul_kernel, dim3(mA), dim3(256), 0, s, pa, (const double*)c.r);     // t (:86-98), then y
+                    hipLaunchKernelGGL(trsv_small_kernel, dim3(1), dim3(256), 0, s, pa);
                 }
+                BH_HIP(hipGetLastError());
                 if (index == 0) {
                     // a = J~ D g: one J v sweep over the masked g.  B = J~ D A' (rows x mA): ONE sweep on the matrix cores
                     // (image_b_mfma_kernel) when the images share their leading dimension, else mA J v sweeps over masked rows of A
@@ -3130,16 +3124,9 @@ static int32_t cauchy_impl(bh_hess* H, bh_proj* P, const double* x, const double
                 CauchyImgGenArgs ga{};
                 ga.b = ia; ga.a = H->timg_gen; ga.B = H->timg_gen + rows_cap; ga.rows_cap = rows_cap; ga.mA = mA;
                 ga.A = P->Ad; ga.ldA = P->ldA; ga.tw = P->tw; ga.g = a.g;
-                if (d_with_rows) {
-                    ProjArgs pa = proj_args(P, c.d_state, true, true);
-                    const int dblocks = ((int)(n + 1) / 2 + 63) / 64;
-                    hipLaunchKernelGGL(cauchy_gen_rows_and_d_kernel, dim3(part_G + dblocks), dim3(256), 0, s, ga, gen_tiled ? 1 : 0, part_G, pa,
-                                       (const double*)c.r, c.p);
-                } else if (gen_tiled) {
-                    hipLaunchKernelGGL(cauchy_image_gen_kernel, dim3(gen_grid), dim3(256), 0, s, ga);
-                } else {
-                    hipLaunchKernelGGL(cauchy_image_gen_rows_kernel, dim3(img_grid), dim3(256), 0, s, ga);
-                }
+                const int dblocks = ((int)(n + 1) / 2 + 63) / 64;
+                hipLaunchKernelGGL(cauchy_gen_rows_and_d_kernel, dim3(part_G + dblocks + mA), dim3(256), 0, s, ga, gen_tiled ? 1 : 0, part_G, dblocks, pa,
+                                   (const double*)c.r, c.p, P->tpart);
             } else {
                 if (index == 0) {
                     BH_TRY(launch_jv(H, c.p, H->timg, true, nullptr));              // t_d = J~ d_0 (:609 in the row space)

@@ -186,14 +186,22 @@ __global__ __launch_bounds__(256) void cauchy_image_gen_kernel(CauchyImgGenArgs 
 }
 // The row kernel and d = P(-g) = -g_free - A_free'y need the same y and nothing of each other: one launch, the first `row_blocks`
 // workgroups take the rows, the others 64 chunks of d each (proj_left_mul_tr_kernel<true, 4>'s arithmetic).
-__global__ __launch_bounds__(256) void cauchy_gen_rows_and_d_kernel(CauchyImgGenArgs ga, int tiled, int row_blocks, ProjArgs pa,
-                                                                   const double* __restrict__ r, double* __restrict__ d_out) {
+// A third group of mA workgroups forms t_fresh = A_free(-g) for the CURRENT active set (left_mul, one row of A each): the next
+// pass's right-hand side is this value minus the column of the variable the decision in between fixes (cauchy_factor_solve_kernel).
+__global__ __launch_bounds__(256) void cauchy_gen_rows_and_d_kernel(CauchyImgGenArgs ga, int tiled, int row_blocks, int d_blocks, ProjArgs pa,
+                                                                   const double* __restrict__ r, double* __restrict__ d_out,
+                                                                   double* __restrict__ t_fresh) {
     if (ga.b.st->done) return;
-    if ((int)blockIdx.x < row_blocks) {
-        if (tiled) cauchy_image_gen_body(ga, (int)blockIdx.x, row_blocks);
-        else cauchy_image_gen_rows_body(ga, (int)blockIdx.x, row_blocks);
+    const int b = (int)blockIdx.x;
+    if (b < row_blocks) {
+        if (tiled) cauchy_image_gen_body(ga, b, row_blocks);
+        else cauchy_image_gen_rows_body(ga, b, row_blocks);
+    } else if (b < row_blocks + d_blocks) {
+        proj_left_mul_tr_body<true, 4>(pa, r, d_out, b - row_blocks);
     } else {
-        proj_left_mul_tr_body<true, 4>(pa, r, d_out, (int)blockIdx.x - row_blocks);
+        ProjArgs pf = pa;
+        pf.tw = t_fresh;
+        proj_left_mul_body(pf, r, b - row_blocks - d_blocks);
     }
 }
 

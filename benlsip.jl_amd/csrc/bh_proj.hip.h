@@ -446,16 +446,6 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const double* Msrc, int
     if (gate != nullptr && gate->done) return;
     chol_small_body(const_cast<double*>(Msrc), ld_src, M, ld_dst, m, dinv_out, info, info_base, reset_info, nullptr, 0, -1);
 }
-// One launch for the two independent small jobs of a Cauchy pass with linear equalities (mA <= 64, reduced form): workgroup 0
-// downdates the Gram matrix by the column of the variable fixed at the last breakpoint and refactors it (the reference rebuilds its
-// factor from scratch at every breakpoint too, :631), workgroups 1 .. mA form t = A_free (-g) row by row (left_mul, :86-98).
-__global__ __launch_bounds__(256) void cauchy_factor_leftmul_kernel(double* Mgram, double* L, int m, int* info, ProjArgs pa,
-                                                                   const double* __restrict__ x, const CgState* st) {
-    if (st->done) return;
-    if (blockIdx.x == 0) chol_small_body(Mgram, m, L, m, m, L + (int64_t)m * m, info, 0, 0, pa.A, pa.ldA, st->status);
-    else proj_left_mul_body(pa, x, (int)blockIdx.x - 1);
-}
-
 // ---- blocked Cholesky for m > 64: potrf (chol_small_kernel on the 64 x 64 diagonal block) / trsm / syrk per panel ------
 // Copy the lower triangle (gate-aware) so that the factorisation can run in place on dst.
 __global__ __launch_bounds__(256) void copy_lower_kernel(const double* __restrict__ src, double* __restrict__ dst, int m, int* info,
@@ -590,8 +580,7 @@ __global__ __launch_bounds__(CG_T) void chol_downdate_kernel(double* __restrict_
 // tw <- L' \ (L \ tw) for m <= 64 (reduced form).  256 threads stage L into an LDS tile (all loads in flight at once,
 // row stride 65: conflict-free both row- and column-wise); wave 0 then runs the 2 x m dependent steps
 // (readlane + LDS read + fma) with the reciprocal diagonal from chol_small_kernel.
-__global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
-    if (proj_skip(a)) return;
+__device__ __forceinline__ void trsv_small_body(const ProjArgs& a) {
     __shared__ double t[64 * 65];
     __shared__ double tq[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = a.mpp;
@@ -647,6 +636,28 @@ __global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
         if (lane < j) xi = fma(-lji, xj, xi);
     }
     if (lane < m) a.tw[lane] = xi;
+}
+__global__ __launch_bounds__(256) void trsv_small_kernel(ProjArgs a) {
+    if (proj_skip(a)) return;
+    trsv_small_body(a);
+}
+// A Cauchy pass with linear equalities (mA <= 64, reduced form), everything that one workgroup does between two decisions, in ONE
+// launch: the Gram matrix downdated by the column of the variable fixed at the last breakpoint and refactored from scratch (as the
+// reference rebuilds its factor at every breakpoint, :631), the right-hand side t = A_free(-g) — the value left_mul formed for the
+// previous active set (t_fresh, computed next to the row kernel of the previous pass) minus the one column that left it, so every t
+// carries exactly one update on top of a fresh sum —, and the two triangular solves: y in a.tw.
+__global__ __launch_bounds__(256) void cauchy_factor_solve_kernel(double* Mgram, double* L, int m, int* info, ProjArgs a,
+                                                                 const double* __restrict__ r, const double* __restrict__ t_fresh,
+                                                                 const CgState* st) {
+    if (st->done) return;
+    const int ind = st->status;
+    double t_mine = 0.0;
+    if ((int)threadIdx.x < m) t_mine = fma(-a.A[(int64_t)threadIdx.x * a.ldA + ind], r[ind], t_fresh[threadIdx.x]);
+    chol_small_body(Mgram, m, L, m, m, L + (int64_t)m * m, info, 0, 0, a.A, a.ldA, ind);
+    if ((int)threadIdx.x < m) a.tw[threadIdx.x] = t_mine;
+    __threadfence_block();
+    __syncthreads();                                       // L, its reciprocal diagonal and t are in memory for the whole workgroup
+    trsv_small_body(a);
 }
 
 // Explicit inverse of the reduced-form factor, m <= 64:  W[0 .. 4096) = Linv column-major (W[k*64 + i] = Linv[i][k]),
