@@ -182,3 +182,34 @@ def test_bench_gpus_n_as_typed_becomes_the_launcher():
     assert r.returncode != 0
     assert "launch with torch.distributed.run" not in r.stderr
     assert "[rank 0]" in r.stderr and "[rank 1]" in r.stderr and "exited with code" in r.stderr
+
+
+def test_stats_struct_matches_the_header(tmp_path):
+    """bh_stats_t as the ctypes mirror declares it against the header, field by field: a small C program compiled against
+    include/benlsip_hip.h prints sizeof and every offsetof; names, order, offsets and total size must agree (a field added on one
+    side only would shift everything behind it silently)."""
+    import ctypes as C
+    import re
+    import subprocess
+    from benlsip_jl_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "benlsip_hip.h")).read()
+    body = re.search(r"typedef struct bh_stats_t \{(.*?)\} bh_stats_t;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r"(int64_t|double)\s+(.*)", decl, re.S)
+        assert m, decl
+        names += [x.strip() for x in m.group(2).split(",")]
+    assert names == [f for f, _ in _lib.bh_stats_t._fields_], (names, [f for f, _ in _lib.bh_stats_t._fields_])
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "benlsip_hip.h"\nint main(void) {\n  printf("%zu\\n", sizeof(bh_stats_t));\n'
+                   + "".join('  printf("%%zu\\n", offsetof(bh_stats_t, %s));\n' % f for f in names) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert out[0] == C.sizeof(_lib.bh_stats_t)
+    assert out[1:] == [getattr(_lib.bh_stats_t, f).offset for f in names]
