@@ -1214,6 +1214,52 @@ def test_gram_on_matrix_cores_matches_valu_path(bh, mA, n, nfix):
     assert np.linalg.norm(out[1] - out[0]) <= tol * np.linalg.norm(r)
 
 
+def test_cauchy_step_vectors_longer_than_one_batch(bh):
+    """n = 9001 (odd, more than the 4096 elements a workgroup of the decision code holds in registers: its batch loop and the strided
+    tail of the s_c update run), box constraints, a gradient with 300 non-zero components so that the oracle's search stays short:
+    every form of the device search against the oracle — breakpoints, active set, step to 1e-9."""
+    rng = np.random.default_rng(16)
+    d, n, q = 120, 9001, 2
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    C = rng.standard_normal((q, n))
+    xlow, xupp = -np.ones(n), np.ones(n)
+    x = np.clip(0.5 * rng.standard_normal(n), -0.95, 0.95)
+    act = rng.choice(n, 60, replace=False)
+    x[act] = np.where(rng.random(60) < 0.5, -1.0, 1.0)
+    g = np.zeros(n)
+    nz = rng.choice(n, 300, replace=False)
+    g[nz] = rng.standard_normal(300)
+    delta = 0.001 * np.linalg.norm(g)            # a tight trust region: 253 passes
+    Z = np.zeros((0, n))
+    L0 = R.chol_lower(Z @ Z.T)
+    Ho = R.AlHessian(J, C, 2.5)
+    cons_o = R.make_mixed_constraints(Z, L0, l=xlow, u=xupp)
+    calls = [0]
+
+    class Ops(R.NumpyOps):
+        def hmul(self, H, v):
+            calls[0] += 1
+            return R.hmul(H, v)
+    s_ref = R.cauchy_step(x, g, Ho, L0, cons_o, delta, Ops())
+    assert calls[0] > 200
+    H = bh.AlHessian(J, C, 2.5)
+    for image, fused in ((1, 1), (1, 0), (0, 0)):
+        bh.set_option("cauchy_image", image)
+        bh.set_option("cauchy_fused", fused)
+        try:
+            cons = bh.MixedConstraints(Z, None, l=xlow, u=xupp)
+            s, info = bh.cauchy_step(x, g, H, cons, delta, full_output=True)
+        finally:
+            bh.set_option("cauchy_image", 1)
+            bh.set_option("cauchy_fused", 1)
+        assert np.array_equal(cons.fixvars, cons_o.fixvars) and info["n_hmul"] == calls[0], (image, fused, info, calls[0])
+        rel = relnorm(s, s_ref)
+        note_tol("cauchy_step (box): step vs oracle, 1e-9", rel, 1e-9, "n=9001 image=%d fused=%d, %d breakpoints" % (image, fused, info["n_breakpoints"]))
+        assert rel <= 1e-9, (image, fused, rel)
+        cons.close()
+    H.close()
+
+
 def test_cauchy_search_forms_agree_at_config3_scale(bh, capsys):
     """The Cauchy search at BASELINE config-3 scale (d = 65536, n = 4096: 128 workgroups of the fused kernel, 512 tiles of the
     equality form — launch shapes the small parity cases never reach), where the oracle would take minutes: the device's own forms
