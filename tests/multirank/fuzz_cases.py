@@ -19,7 +19,7 @@ def cases(seed, count):
         if r < 0.12:
             d = int(rng.integers(1, 4))                   # fewer rows than ranks: some ranks own nothing
         elif r < 0.3:
-            d = int(rng.integers(4, n + 2))               # rank-deficient H: zero / negative-curvature exits
+            d = int(rng.integers(4, max(n + 2, 5)))       # rank-deficient H: zero / negative-curvature exits
         else:
             d = int(rng.integers(2 * n, 5 * n + 2))
         q = int(rng.integers(0, 3))
