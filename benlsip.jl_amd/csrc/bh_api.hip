@@ -111,6 +111,7 @@ struct Ctx {
     int64_t opt_cauchy_image_max_ma = 64;   // ... and with up to this many linear equalities (0..64)
     int64_t opt_cauchy_fused = 1;           // box constraints, one rank, row-space form: ONE kernel per breakpoint (cauchy_fused_kernel)
     int64_t opt_cauchy_fused_grid = 0;      // experiment: workgroups of cauchy_fused_kernel (0: one row per thread up to kCauchyFusedGrid)
+    int64_t opt_linv_refine = 1;            // explicit-inverse projection (three-kernel CG iteration): one step of iterative refinement of y
     int64_t opt_cauchy_gemm = 1;            // B = J D A' of that form in one sweep on the matrix cores (0: mA J v sweeps over masked rows of A)
     int64_t opt_gram_mfma = 1;       // A_free A_free': 1 = matrix cores when mA > 96, 2 = always, 0 = never (one wave per entry, VALU)
     int64_t opt_ls_from_cg = 1;      // minor_iterate: linesearch's w'Hw from the H*w accumulated by the CG loop
@@ -1368,6 +1369,7 @@ int32_t bh_set_option(const char* key, int64_t value) {
     if (!strcmp(key, "cauchy_image")) { g_ctx.opt_cauchy_image = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_fused")) { g_ctx.opt_cauchy_fused = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_fused_grid")) { g_ctx.opt_cauchy_fused_grid = std::min<int64_t>(std::max<int64_t>(0, value), kCauchyFusedGrid); return BH_OK; }
+    if (!strcmp(key, "linv_refine")) { g_ctx.opt_linv_refine = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_gemm")) { g_ctx.opt_cauchy_gemm = value ? 1 : 0; return BH_OK; }
     if (!strcmp(key, "cauchy_image_max_ma")) { g_ctx.opt_cauchy_image_max_ma = std::min<int64_t>(std::max<int64_t>(0, value), 64); return BH_OK; }
     if (!strcmp(key, "chol_blocked")) { g_ctx.opt_chol_blocked = value ? 1 : 0; return BH_OK; }
@@ -2187,7 +2189,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             ProjArgs pa = proj_args(P, nullptr, true);
             hipLaunchKernelGGL(proj_left_mul_kernel, dim3((unsigned)P->mA), dim3(256), 0, s, pa, gp);
             pa.tpart = P->tw; pa.tpart_nblk = 1; pa.rvpart = rvbuf[0]; pa.vvpart = rvbuf[0] + vv_off; pa.p_out = c.p;
-            pa.W = P->W; pa.nch_pad = H->nchunks; pa.fused_j = 0;
+            pa.W = P->W; pa.nch_pad = H->nchunks; pa.Mgram = (g_ctx.opt_linv_refine && P->M_valid) ? P->M : nullptr; pa.fused_j = 0;
             hipLaunchKernelGGL((proj_apply_linv_kernel<true>), dim3((unsigned)nrv), dim3(256), 0, s, pa, gp, c.v);
         } else if (fuse_gen) {
             // :702-718 by the init kernels: r = g, w = 0, v = P(r), rtv, p_1 = -v (in c.p), tol_cg, CgState (stop_at = 0)
@@ -2244,7 +2246,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             ProjArgs pa = proj_args(P, c.d_state, true);
             pa.tpart = P->tpart; pa.tpart_nblk = nblk; pa.rvpart = rvbuf[j & 1]; pa.fused_j = j;
             if (gen_linv) {
-                pa.W = P->W; pa.nch_pad = H->nchunks;
+                pa.W = P->W; pa.nch_pad = H->nchunks; pa.Mgram = (g_ctx.opt_linv_refine && P->M_valid) ? P->M : nullptr;
                 hipLaunchKernelGGL((proj_apply_linv_kernel<false>), dim3((unsigned)nrv), dim3(256), 0, s, pa, (const double*)c.r, c.v);
                 return BH_OK;
             }

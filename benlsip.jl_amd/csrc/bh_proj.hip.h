@@ -32,6 +32,7 @@ struct ProjArgs {
     double* vvpart;         // INIT: this workgroup's partial of v.v (tol_cg = kappa2*||v||, :710)
     double* p_out;          // INIT: p_1 = -v (:708)
     int nch_pad;            // chunks per padded vector (ld / 2): the kernel keeps [n, ld) of its outputs at zero
+    const double* Mgram;    // A_free A_free' (lower triangle, column-major mA x mA) for one step of iterative refinement of y; NULL: none
 };
 
 __device__ __forceinline__ bool proj_skip(const CgState* st) { return st != nullptr && (st->done || !st->need_proj); }
@@ -777,6 +778,14 @@ __global__ __launch_bounds__(256) void proj_apply_linv_kernel(ProjArgs a, const 
     const double2 rk = reinterpret_cast<const double2*>(r)[cc];
     int2 fr = make_int2(-1, -1);
     if (a.fixrank != nullptr) fr = reinterpret_cast<const int2*>(a.fixrank)[cc];
+    // row cl of the (symmetric) Gram matrix, entries 16 rg .. 16 rg + 15, for the refinement step below
+    const bool refine = a.Mgram != nullptr;
+    double mg[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int kk = min(16 * rg + k, m - 1), ii = min(cl, m - 1);
+        mg[k] = refine ? a.Mgram[(ii >= kk) ? (ii + (int64_t)kk * m) : (kk + (int64_t)ii * m)] : 0.0;
+    }
     {
         double acc = 0.0;
 #pragma unroll
@@ -811,6 +820,34 @@ __global__ __launch_bounds__(256) void proj_apply_linv_kernel(ProjArgs a, const 
     __syncthreads();
     if (rg == 0) ys[cl] = (tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl]);
     __syncthreads();
+    if (refine) {
+        // ---- one step of iterative refinement: rho = t - M y, y += Linv'(Linv rho).  The explicit inverse leaves a residual of the
+        //      normal equations of order cond(M) eps (measured: |A_free v| 100 - 10^5 x that of the triangular solves once
+        //      cond(A_free A_free') reaches 10^9 - 10^15, tests/manual/illcond_probe.py); the correction brings A_free v back to the
+        //      level of the reference's two substitutions.  Three more 64-term dot products per entry.
+        acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (16 * rg + k < m) acc = fma(mg[k], ys[16 * rg + k], acc);
+        tq[rg][cl] = acc;
+        __syncthreads();
+        if (rg == 0) ts[cl] = (cl < m) ? ts[cl] - ((tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl])) : 0.0;
+        __syncthreads();
+        acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(w1[k], ts[16 * rg + k], acc);
+        tq[rg][cl] = acc;
+        __syncthreads();
+        if (rg == 0) us[cl] = (tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl]);
+        __syncthreads();
+        acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fma(w2[k], us[16 * rg + k], acc);
+        tq[rg][cl] = acc;
+        __syncthreads();
+        if (rg == 0) ys[cl] += (tq[0][cl] + tq[1][cl]) + (tq[2][cl] + tq[3][cl]);
+        __syncthreads();
+    }
     // ---- left_mul_tr on this workgroup's chunks (rows rg, rg + 4, ...: the order of proj_left_mul_tr_kernel<true, 4>) -------------
     double2 z = make_double2(0.0, 0.0);
 #pragma unroll

@@ -262,6 +262,20 @@ class ShadowOps:
                 g2 = g * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, g.shape[0]))
                 s2 = R.cauchy_step(x, g2, H[1], chol_aat_L, sh2, delta, self.cpu)
                 sens = max(sens, float(np.linalg.norm(s2 - s_o) / max(np.linalg.norm(s_o), 1e-300)))
+            # ... and when the SAME projector is evaluated in its reduced form (mask, then chol(A_free A_free'): mathematically the
+            # reference's augmented form, rounded differently — the form the device uses)?  Near a critical point phi' = g'd is
+            # -|d|^2 + g'(error of d), so two exact-arithmetic-identical projectors disagree on the second segment's minimiser by
+            # eps |g|^2 / |d|^2 (measured on config 1: 12 % at |g|/|P(-g)| = 8e6, while 1-ulp perturbations of g move the augmented
+            # form by 1e-9: tests/manual/sphere_cauchy_event_probe.py).  The oracle FAMILY's spread is what a device can be held to.
+            from _util import ReducedFormOps
+            for k in range(max(2, self.n_cauchy_samples // 4)):
+                sh2 = copy.copy(lincons)
+                sh2._dev = None
+                sh2.fixvars = fix0.copy()
+                sh2.chol_L = chol0
+                g2 = g if k == 0 else g * (1.0 + 2.2e-16 * rng.uniform(-1.0, 1.0, g.shape[0]))
+                s2 = R.cauchy_step(x, g2, H[1], chol_aat_L, sh2, delta, ReducedFormOps())
+                sens = max(sens, float(np.linalg.norm(s2 - s_o) / max(np.linalg.norm(s_o), 1e-300)))
             red = self.cpu.projection(shadow, -g)
             self.events.append(dict(op="cauchy_step", minor=self.minor, rel=d, oracle_sensitivity=sens,
                                     fix_dev=int(lincons.fixvars.sum()), fix_cpu=int(shadow.fixvars.sum()),

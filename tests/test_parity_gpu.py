@@ -480,6 +480,52 @@ def test_pcg_random_instances(bh, cg_fused, d, n, q, mA, nfix, seed):
     H.close()
 
 
+@pytest.mark.parametrize("dep,cond_min", [(1e-4, 1e8), (1e-6, 1e12)])
+def test_pcg_ill_conditioned_equalities_stay_feasible(bh, dep, cond_min):
+    """Rows of A nearly dependent (cond(A A') = 1e9 / 1e13).  The step w must stay in null(A) as well as the reference's two
+    triangular solves keep it there (src/polyhedral_constraints.jl:114-115): the default three-kernel iteration applies the explicit
+    inverse of the factor, which alone left |A w| 100 - 4000 x larger (1.7e-10 against 1.0e-12, 2.0e-7 against 4.7e-11:
+    tests/manual/illcond_probe.py), and repairs it with one step of iterative refinement (option linv_refine).  Held to 10 x the
+    larger of the oracle's and the triangular-solve shape's own |A w|/|A||w|; status and iteration count as the oracle's where the
+    oracle itself is stable under an LU projector."""
+    rng = np.random.default_rng(3)
+    d, n, mA = 600, 300, 12
+    J = rng.standard_normal((d, n)) / np.sqrt(d)
+    g = rng.standard_normal(n)
+    A = rng.standard_normal((mA, n))
+    A[1] = A[0] + dep * rng.standard_normal(n)
+    A[5] = A[4] - A[3] + dep * rng.standard_normal(n)
+    M = A @ A.T
+    assert np.linalg.cond(M) > cond_min
+    cons_o = R.make_mixed_constraints(A, R.chol_lower(M), None, l=-np.ones(n), u=np.ones(n))
+    wl, wu = -10.0 * np.ones(n), 10.0 * np.ones(n)
+    Ho = R.AlHessian(J, np.zeros((0, n)), 1.0)
+    w_ref, st_ref, it_ref = R.projected_cg(g, Ho, wl, wu, cons_o, 1e-3)
+    w_lu, st_lu, it_lu = R.projected_cg(g, Ho, wl, wu, cons_o, 1e-3, proj_fn=lambda cons, r: r - A.T @ np.linalg.solve(M, A @ r))
+    feas = lambda w: float(np.linalg.norm(A @ w) / (np.linalg.norm(A) * np.linalg.norm(w)))
+    H = bh.AlHessian(J, None, 1.0)
+    out = {}
+    for fused in (1, 2):
+        bh.set_option("cg_fused", fused)
+        try:
+            cons = bh.MixedConstraints(A, None, None, l=-np.ones(n), u=np.ones(n))
+            w, st, info = bh.projected_cg(g, H, wl, wu, cons, 1e-3, full_output=True)
+        finally:
+            bh.set_option("cg_fused", 1)
+        out[fused] = (w, int(st), info["iters"])
+        cons.close()
+    H.close()
+    bound = 10.0 * max(feas(w_ref), feas(out[2][0])) + 1e-15
+    note_tol("ill-conditioned equalities: |A w|/|A||w| of the explicit-inverse iteration vs 10 x (oracle, triangular solves)", feas(out[1][0]), bound,
+             "cond(A A') = %.1e: device %.1e, triangular solves %.1e, oracle %.1e" % (np.linalg.cond(M), feas(out[1][0]), feas(out[2][0]), feas(w_ref)))
+    assert feas(out[1][0]) <= bound, (feas(out[1][0]), feas(out[2][0]), feas(w_ref))
+    assert out[1][1] == out[2][1] == int(st_ref)
+    if (int(st_lu), it_lu) == (int(st_ref), it_ref):          # the oracle's own count is stable under another projector arithmetic
+        assert out[1][2] == out[2][2]
+        drift = max(relnorm(w_lu, w_ref), 1e-12)
+        assert relnorm(out[1][0], w_ref) <= 1e3 * drift and relnorm(out[1][0], out[2][0]) <= 1e3 * drift
+
+
 @pytest.mark.parametrize("d,n,nfix,kappa2", [(60, 5000, 300, 0.1), (40, 8192, 0, 0.1), (50, 9001, 700, 0.1), (30, 16384, 1000, 0.3),
                                              (33, 16385, 5, 0.3), (2000, 2048, 100, 0.01), (700, 1000, 7, 0.01)])
 def test_pcg_wide_rows_every_kernel_geometry(bh, cg_fused, d, n, nfix, kappa2):
@@ -680,8 +726,10 @@ def test_sphere_regression_shadow_solve_every_variant(bh, capsys, ops_cls, fused
       * every projected_cg / minor iterate has the oracle's exit status and iteration count, every Cauchy search the oracle's
         final active set — no exception;
       * w and the Cauchy step are cancelling computations near the solution (measured here: the ORACLE's own w moves by up to
-        2e-6, its Cauchy step by up to 6e-2, when g is perturbed by one unit in the last place — at n = 3): they must lie within
-        8 x the spread of 16 such perturbed oracle evaluations (or 1e-12), the used fraction is printed."""
+        2e-6, its Cauchy step by up to 6e-2, when g is perturbed by one unit in the last place — at n = 3; and by 12 % when the same
+        projector is evaluated in its reduced form instead of the augmented one, tests/manual/sphere_cauchy_event_probe.py): they
+        must lie within 8 x the spread of the oracle family's evaluations (16 perturbed ones, for the Cauchy step also in the
+        reduced form of the projector; or 1e-12), the used fraction is printed."""
     bh.set_option("cg_fused", fused)
     try:
         sh = ShadowOps(ops_cls(bh), relnorm_tol=1e-12, sens_samples=16)
