@@ -2158,6 +2158,8 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
     // then left_mul_tr.  Both change pHp's rounding like the box form does (cg_fused = 0 keeps dot(p, H*p)).
     const bool fuse_gen = !box && g_ctx.opt_cg_fused >= 1 && P->reduced && P->mA <= 64 && P->tpart != nullptr && P->ldA == H->ld;
     const bool gen_linv = fuse_gen && g_ctx.opt_cg_fused == 1 && P->W != nullptr;
+    // (one equality: the "factor" is a scalar, y = t / l^2 has no conditioning to repair — the refinement step would only move the last bit)
+    const bool linv_refine = gen_linv && g_ctx.opt_linv_refine != 0 && P->M_valid && P->mA >= 2;
     // Several ranks: the two-kernel (equalities: three-kernel) form carries the exchange inside the update kernel when the
     // peer-buffer transport is the active one (cg_reduce_update_kernel<GEN, true>: push the workgroup's 32 columns + its rank's share of pHp, wait, sum in
     // rank order); an RCCL all-reduce cannot sit inside a kernel, so that path keeps the three-kernel form.
@@ -2189,7 +2191,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             ProjArgs pa = proj_args(P, nullptr, true);
             hipLaunchKernelGGL(proj_left_mul_kernel, dim3((unsigned)P->mA), dim3(256), 0, s, pa, gp);
             pa.tpart = P->tw; pa.tpart_nblk = 1; pa.rvpart = rvbuf[0]; pa.vvpart = rvbuf[0] + vv_off; pa.p_out = c.p;
-            pa.W = P->W; pa.nch_pad = H->nchunks; pa.Mgram = (g_ctx.opt_linv_refine && P->M_valid) ? P->M : nullptr; pa.fused_j = 0;
+            pa.W = P->W; pa.nch_pad = H->nchunks; pa.Mgram = linv_refine ? P->M : nullptr; pa.fused_j = 0;
             hipLaunchKernelGGL((proj_apply_linv_kernel<true>), dim3((unsigned)nrv), dim3(256), 0, s, pa, gp, c.v);
         } else if (fuse_gen) {
             // :702-718 by the init kernels: r = g, w = 0, v = P(r), rtv, p_1 = -v (in c.p), tol_cg, CgState (stop_at = 0)
@@ -2246,7 +2248,7 @@ static int32_t pcg_run(bh_hess* H, bh_proj* P, const double* gp, const double* w
             ProjArgs pa = proj_args(P, c.d_state, true);
             pa.tpart = P->tpart; pa.tpart_nblk = nblk; pa.rvpart = rvbuf[j & 1]; pa.fused_j = j;
             if (gen_linv) {
-                pa.W = P->W; pa.nch_pad = H->nchunks; pa.Mgram = (g_ctx.opt_linv_refine && P->M_valid) ? P->M : nullptr;
+                pa.W = P->W; pa.nch_pad = H->nchunks; pa.Mgram = linv_refine ? P->M : nullptr;
                 hipLaunchKernelGGL((proj_apply_linv_kernel<false>), dim3((unsigned)nrv), dim3(256), 0, s, pa, (const double*)c.r, c.v);
                 return BH_OK;
             }

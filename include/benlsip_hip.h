@@ -358,7 +358,8 @@ int32_t bh_stats_reset(bh_hess* H);
  *   "cauchy_fused_grid" [0] workgroups of that kernel (0: one row per thread up to 256 workgroups; measured best — tools/scratch/cauchy_grid_sweep.py)
  *   "linv_refine"    [1] three-kernel CG iteration with linear equalities (cg_fused = 1): one step of iterative refinement behind the
  *                        explicit inverse of the factor (rho = t - A_free A_free' y, y += L^-T L^-1 rho), so that A_free v stays at the level
- *                        of the reference's two triangular solves also for ill-conditioned A_free A_free' (0: plain explicit inverse)
+ *                        of the reference's two triangular solves also for ill-conditioned A_free A_free' (0: plain explicit inverse;
+ *                        not applied with a single equality, where the factor is a scalar)
  *   "cauchy_gemm"    [1] B = J D A' in ONE sweep over J on the fp64 matrix cores (a tall-skinny GEMM: M = rows of J, N = mA, K = n);
  *                        0: mA J v sweeps over the masked rows of A
  *   "chol_blocked"   [1] mA > 64: blocked potrf / trsm / syrk (0: one-workgroup kernel)

@@ -699,7 +699,7 @@ def test_sphere_regression_through_c_abi(bh, capsys, ops_cls):
     # test_reference_bound_on_config_1_is_decided_by_rounding_in_the_oracle_itself), because the last trust-region iterates
     # accept / resize on rho = ared/pred with |ared| worth 3-4 ulps of mx (printed below: first differing decision).  Which
     # side a device variant ends on has flipped with unrelated kernel edits (round 2: 6.8e-8 / 3.15e-7; round 3: 4.2e-8 ...
-    # 7.8e-8 on all four).  ONE rule for every variant, with the band computed here: within a factor 2 of the largest value the
+    # 7.8e-8 on all four mid-round, 4.2e-8 / 7.8e-8 / 2.8e-7 / 2.8e-7 after the Cauchy kernels were rewritten).  ONE rule for every variant, with the band computed here: within a factor 2 of the largest value the
     # oracle's own re-associations produce; whether the reference's 1e-7 is met is printed, not fitted.
     from _util import assert_rounding_dominated, first_decision_difference, sphere_oracle_band
     log_ref = []
