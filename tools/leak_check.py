@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device-memory leak check: 240 create / use / destroy cycles of AlHessian (synchronous and asynchronous ingest) and
-MixedConstraints handles of random sizes; hipMemGetInfo after every 40 (free memory must come back to where it was, give or
+MixedConstraints handles of random sizes, with a projection, a projected_cg and a Cauchy search on each; hipMemGetInfo after every 40 (free memory must come back to where it was, give or
 take the image pool's parked buffers)."""
 import ctypes as C, sys, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +25,10 @@ for rep in range(6):
         cons.set_active(fix, None)
         _ = bh.projection(cons, v)
         w, st = bh.projected_cg(v, H, -np.ones(n), np.ones(n), cons, 0.1)
-        H.close(); cons.close()
+        # the Cauchy search allocates its row-space vectors (and, with equalities, the rows x (1 + mA) set-up block) on the handle
+        cau = bh.MixedConstraints(rng.standard_normal((mA, n)), None, None, l=-np.ones(n), u=np.ones(n))
+        _ = bh.cauchy_step(np.zeros(n), v, H, cau, 0.3 * np.linalg.norm(v))
+        H.close(); cons.close(); cau.close()
     bh._lib.lib().bh_synchronize()
     f = free_mb()
     if base is None: base = f
