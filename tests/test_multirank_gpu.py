@@ -69,7 +69,7 @@ def build_stand_in():
     return so
 
 
-@pytest.mark.parametrize("comm,world", [("ipc", 2), ("ipc", 3), ("ipc", 4), ("staged", 2)])
+@pytest.mark.parametrize("comm,world", [("ipc", 2), ("ipc", 3), ("ipc", 4), ("ipc", 5), ("staged", 2), ("staged", 3)])
 def test_row_sharded_library_in_separate_processes(tmp_path, comm, world):
     from problem import make_problem
     run_ranks("worker.py", world, tmp_path, comm)
