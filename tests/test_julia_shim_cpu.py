@@ -156,3 +156,70 @@ def test_the_checker_catches_a_transposed_argument():
     assert not all(compatible(julia_class(t), c) for t, c in zip(bad, p["params"]))
     assert not compatible(julia_class("Ref{Int32}"), "ptr:f64") and not compatible(julia_class("Ref{Ptr{Cvoid}}"), "ptr:any")
     assert compatible(julia_class("Ptr{Cvoid}"), "ptr:f64") and compatible(julia_class("Ptr{UInt8}"), "ptr:any")
+
+
+def _strip_julia(src):
+    """Comments, string and character literals blanked out (newlines kept), so that keywords and brackets can be counted."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("#=", i):
+            j = src.find("=#", i + 2)
+            j = n if j < 0 else j + 2
+            out.append("".join(ch if ch == "\n" else " " for ch in src[i:j])); i = j
+        elif c == "#":
+            j = src.find("\n", i)
+            j = n if j < 0 else j
+            out.append(" " * (j - i)); i = j
+        elif src.startswith('"""', i):
+            j = src.find('"""', i + 3)
+            j = n if j < 0 else j + 3
+            out.append("".join(ch if ch == "\n" else " " for ch in src[i:j])); i = j
+        elif c == '"':
+            j = i + 1
+            while j < n and src[j] != '"':
+                j += 2 if src[j] == "\\" else 1
+            out.append('""' + " " * (j - i - 1)); i = j + 1
+        elif c == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src.find("'", i + 2) in (i + 3, i + 4))):
+            j = src.find("'", i + 2)
+            out.append(" " * (j - i + 1)); i = j + 1            # a character literal ('x', '\n'); a lone ' is the adjoint operator
+        else:
+            out.append(c); i += 1
+    return "".join(out)
+
+
+def test_julia_shim_blocks_and_brackets_balance():
+    """No Julia toolchain exists in this pipeline, so the shim has never been parsed by Julia.  The next best mechanical check: after
+    blanking comments and literals, every block opener at bracket depth 0 (function, macro, if, for, while, let, begin, try, struct,
+    module, quote, do) has its `end`, `end` inside [...] is an index, and (), [], {} nest and close — a missing `end` or a stray
+    bracket anywhere in the file fails here."""
+    import re
+    src = _strip_julia(open(os.path.join(ROOT, "julia", "BEnlsipHIP.jl")).read())
+    openers = {"function", "macro", "if", "for", "while", "let", "begin", "try", "struct", "module", "baremodule", "quote", "do"}
+    stack, blocks = [], []
+    pairs = {")": "(", "]": "[", "}": "{"}
+    line = 1
+    for m in re.finditer(r"\n|[A-Za-z_][A-Za-z_0-9!]*|[()\[\]{}]|:[A-Za-z_]\w*", src):
+        tok = m.group(0)
+        if tok == "\n":
+            line += 1
+        elif tok in "([{":
+            stack.append((tok, line))
+        elif tok in ")]}":
+            assert stack and stack[-1][0] == pairs[tok], "unbalanced %r in line %d (open: %s)" % (tok, line, stack[-3:])
+            stack.pop()
+        elif tok.startswith(":"):
+            continue                                             # a symbol such as :end or :function
+        elif tok in openers and not stack:
+            prev = src[max(0, m.start() - 8):m.start()]
+            if tok == "struct" and prev.rstrip().endswith("mutable"):
+                pass
+            blocks.append((tok, line))
+        elif tok == "end":
+            if any(b == "[" for b, _ in stack):
+                continue                                         # a[end]
+            assert not stack, "`end` inside brackets in line %d" % line
+            assert blocks, "`end` without an opener in line %d" % line
+            blocks.pop()
+    assert not stack, "unclosed brackets: %s" % stack[-3:]
+    assert not blocks, "blocks without `end`: %s" % blocks[-5:]
