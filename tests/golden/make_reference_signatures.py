@@ -1,0 +1,53 @@
+"""Writes tests/golden/reference_signatures.json: for every `function name(...)` in the reference's live source files, its name and
+the number and names of its POSITIONAL parameters (keywords after `;` listed separately).  Data about the reference's interface — what
+the Julia shim's more specific methods must line up with — not its source.  Run here (needs /root/reference); the fixture is committed.
+    python tests/golden/make_reference_signatures.py"""
+import json
+import os
+import re
+
+REF = "/root/reference/src"
+FILES = ["basic_tralcnlss.jl", "polyhedral_constraints.jl"]
+
+
+def split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def signatures(text):
+    sigs = []
+    for m in re.finditer(r"^function\s+([A-Za-z_][\w!.:*]*)\s*\(", text, re.M):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        inner = text[m.end():i - 1]
+        pos, _, kw = inner.partition(";")
+        names = lambda lst: [re.split(r"::|=", a)[0].strip() for a in lst]
+        sigs.append({"name": m.group(1), "positional": names(split_args(pos)), "keywords": names(split_args(kw))})
+    return sigs
+
+
+def main():
+    out = {}
+    for f in FILES:
+        out[f] = signatures(open(os.path.join(REF, f)).read())
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_signatures.json")
+    json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+    print({f: len(v) for f, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -223,3 +223,37 @@ def test_julia_shim_blocks_and_brackets_balance():
             blocks.pop()
     assert not stack, "unclosed brackets: %s" % stack[-3:]
     assert not blocks, "blocks without `end`: %s" % blocks[-5:]
+
+
+def test_shim_methods_line_up_with_the_reference_interface():
+    """A more specific method only shadows the reference's if Julia's dispatch finds it: same function name, same number of positional
+    parameters (a mismatch would not raise — the reference's own CPU method would silently keep running).  Every `function
+    BEnlsip.name(...)` / `Base.:*` of the shim against tests/golden/reference_signatures.json (names and arities of the reference's
+    functions, written by tests/golden/make_reference_signatures.py): a function of that name with that many positional parameters
+    exists, parameter names agree in order, and keywords the shim accepts are keywords of the reference's method.  Where the
+    reference tree is present the fixture is regenerated and must be unchanged."""
+    import importlib.util
+    import json
+    import re
+    gold = os.path.join(ROOT, "tests", "golden")
+    ref = json.load(open(os.path.join(gold, "reference_signatures.json")))
+    spec = importlib.util.spec_from_file_location("mrs", os.path.join(gold, "make_reference_signatures.py"))
+    mrs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mrs)
+    if os.path.isdir(mrs.REF):
+        assert {f: mrs.signatures(open(os.path.join(mrs.REF, f)).read()) for f in mrs.FILES} == ref, "fixture out of date: rerun make_reference_signatures.py"
+    by_name = {}
+    for sigs in ref.values():
+        for s in sigs:
+            by_name.setdefault(s["name"].split(".")[-1].lstrip(":"), []).append(s)
+    src = _strip_julia(open(os.path.join(ROOT, "julia", "BEnlsipHIP.jl")).read())
+    shim = [s for s in mrs.signatures(src) if s["name"].startswith(("BEnlsip.", "Base."))]
+    assert len(shim) >= 13
+    for s in shim:
+        name = s["name"].split(".")[-1].lstrip(":")
+        cands = [r for r in by_name.get(name, []) if len(r["positional"]) == len(s["positional"])]
+        assert cands, "shim method %s/%d has no counterpart in the reference (candidates: %s)" % (
+            s["name"], len(s["positional"]), [(r["name"], len(r["positional"])) for r in by_name.get(name, [])])
+        assert any(r["positional"] == s["positional"] for r in cands), (s["name"], s["positional"], [r["positional"] for r in cands])
+        for kw in s["keywords"]:
+            assert any(kw in r["keywords"] for r in cands), (s["name"], kw)
