@@ -1,5 +1,5 @@
 """Writes tests/golden/reference_signatures.json: for every `function name(...)` in the reference's live source files, its name and
-the number and names of its POSITIONAL parameters (keywords after `;` listed separately).  Data about the reference's interface — what
+the number, names and type annotations of its POSITIONAL parameters (keywords after `;` listed separately).  Data about the reference's interface — what
 the Julia shim's more specific methods must line up with — not its source.  Run here (needs /root/reference); the fixture is committed.
     python tests/golden/make_reference_signatures.py"""
 import json
@@ -36,7 +36,8 @@ def signatures(text):
         inner = text[m.end():i - 1]
         pos, _, kw = inner.partition(";")
         names = lambda lst: [re.split(r"::|=", a)[0].strip() for a in lst]
-        sigs.append({"name": m.group(1), "positional": names(split_args(pos)), "keywords": names(split_args(kw))})
+        types = lambda lst: [re.sub(r"\s+", "", re.split(r"=", a.split("::", 1)[1])[0]) if "::" in a else "" for a in lst]
+        sigs.append({"name": m.group(1), "positional": names(split_args(pos)), "types": types(split_args(pos)), "keywords": names(split_args(kw))})
     return sigs
 
 

@@ -230,7 +230,8 @@ def test_shim_methods_line_up_with_the_reference_interface():
     parameters (a mismatch would not raise — the reference's own CPU method would silently keep running).  Every `function
     BEnlsip.name(...)` / `Base.:*` of the shim against tests/golden/reference_signatures.json (names and arities of the reference's
     functions, written by tests/golden/make_reference_signatures.py): a function of that name with that many positional parameters
-    exists, parameter names agree in order, and keywords the shim accepts are keywords of the reference's method.  Where the
+    exists, parameter names agree in order, every type annotation is the reference's with T = Float64, and keywords the shim
+    accepts are keywords of the reference's method.  Where the
     reference tree is present the fixture is regenerated and must be unchanged."""
     import importlib.util
     import json
@@ -254,6 +255,13 @@ def test_shim_methods_line_up_with_the_reference_interface():
         cands = [r for r in by_name.get(name, []) if len(r["positional"]) == len(s["positional"])]
         assert cands, "shim method %s/%d has no counterpart in the reference (candidates: %s)" % (
             s["name"], len(s["positional"]), [(r["name"], len(r["positional"])) for r in by_name.get(name, [])])
-        assert any(r["positional"] == s["positional"] for r in cands), (s["name"], s["positional"], [r["positional"] for r in cands])
+        match = [r for r in cands if r["positional"] == s["positional"]]
+        assert match, (s["name"], s["positional"], [r["positional"] for r in cands])
         for kw in s["keywords"]:
             assert any(kw in r["keywords"] for r in cands), (s["name"], kw)
+        # each annotation is the reference's with T = Float64 (function-typed parameters F1.. keep their own type variables; an
+        # unparametrised `AlHessian` in the reference may be narrowed): more specific, never a different container
+        for a, ts, tr in zip(s["positional"], s["types"], match[0]["types"]):
+            want = re.sub(r"\bT\b", "Float64", tr)
+            got = ts.replace("BEnlsip.", "")
+            assert got == want or (want and "{" not in want and got.startswith(want + "{")) or re.fullmatch(r"F\d", got), (s["name"], a, ts, tr)
