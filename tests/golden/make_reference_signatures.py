@@ -1,5 +1,5 @@
 """Writes tests/golden/reference_signatures.json: for every `function name(...)` in the reference's live source files, its name and
-the number, names and type annotations of its POSITIONAL parameters (keywords after `;` listed separately).  Data about the reference's interface — what
+the number, names and type annotations of its POSITIONAL parameters (keywords after `;` listed separately); the field names of its structs and the members of `CG_status`.  Data about the reference's interface — what
 the Julia shim's more specific methods must line up with — not its source.  Run here (needs /root/reference); the fixture is committed.
     python tests/golden/make_reference_signatures.py"""
 import json
@@ -41,13 +41,32 @@ def signatures(text):
     return sigs
 
 
-def main():
+def struct_fields(text):
+    """{struct name: [field names]} of the `struct ... end` blocks (plain `name::Type` lines)."""
+    out = {}
+    for m in re.finditer(r"^(?:mutable\s+)?struct\s+([A-Za-z_]\w*)[^\n]*\n(.*?)^end", text, re.M | re.S):
+        out[m.group(1)] = [ln.split("::")[0].strip() for ln in m.group(2).splitlines() if "::" in ln and not ln.strip().startswith("#")]
+    return out
+
+
+def build():
     out = {}
     for f in FILES:
         out[f] = signatures(open(os.path.join(REF, f)).read())
+    out["struct_fields"] = {}
+    for f in FILES:
+        out["struct_fields"].update(struct_fields(open(os.path.join(REF, f)).read()))
+    enum = re.search(r"@enum\s+CG_status\s+([^\n]+)", open(os.path.join(REF, FILES[0])).read())
+    out["CG_status"] = enum.group(1).split()
+    return out
+
+
+def main():
+    out = build()
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_signatures.json")
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
     print({f: len(v) for f, v in out.items()})
+    print(out["struct_fields"], out["CG_status"])
 
 
 if __name__ == "__main__":

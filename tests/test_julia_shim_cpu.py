@@ -242,10 +242,10 @@ def test_shim_methods_line_up_with_the_reference_interface():
     mrs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mrs)
     if os.path.isdir(mrs.REF):
-        assert {f: mrs.signatures(open(os.path.join(mrs.REF, f)).read()) for f in mrs.FILES} == ref, "fixture out of date: rerun make_reference_signatures.py"
+        assert mrs.build() == ref, "fixture out of date: rerun make_reference_signatures.py"
     by_name = {}
-    for sigs in ref.values():
-        for s in sigs:
+    for fname in mrs.FILES:
+        for s in ref[fname]:
             by_name.setdefault(s["name"].split(".")[-1].lstrip(":"), []).append(s)
     src = _strip_julia(open(os.path.join(ROOT, "julia", "BEnlsipHIP.jl")).read())
     shim = [s for s in mrs.signatures(src) if s["name"].startswith(("BEnlsip.", "Base."))]
@@ -265,3 +265,21 @@ def test_shim_methods_line_up_with_the_reference_interface():
             want = re.sub(r"\bT\b", "Float64", tr)
             got = ts.replace("BEnlsip.", "")
             assert got == want or (want and "{" not in want and got.startswith(want + "{")) or re.fullmatch(r"F\d", got), (s["name"], a, ts, tr)
+
+
+def test_shim_touches_only_fields_and_enum_members_the_reference_has():
+    """Every `H.x` / `lincons.x` the shim reads is a field of the reference's AlHessian / MixedConstraints, and every CG status it
+    constructs is a member of the reference's `@enum CG_status` (tests/golden/reference_signatures.json)."""
+    import json
+    import re
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))
+    src = _strip_julia(open(os.path.join(ROOT, "julia", "BEnlsipHIP.jl")).read())
+    fields = ref["struct_fields"]
+    used_h = set(re.findall(r"\bH\.([A-Za-z_]\w*)", src))
+    used_l = set(re.findall(r"\blincons\.([A-Za-z_]\w*)", src))
+    assert used_h and used_h <= set(fields["AlHessian"]), (used_h, fields["AlHessian"])
+    assert used_l and used_l <= set(fields["MixedConstraints"]), (used_l, fields["MixedConstraints"])
+    members = set(ref["CG_status"])
+    assert members == {"solved", "bound_hit", "negative_curvature", "max_iter_reached"}
+    for name in re.findall(r"BEnlsip\.(solved|bound_hit|negative_curvature|max_iter_reached|[a-z_]+_reached)\b", src):
+        assert name in members, name
