@@ -281,5 +281,10 @@ def test_shim_touches_only_fields_and_enum_members_the_reference_has():
     assert used_l and used_l <= set(fields["MixedConstraints"]), (used_l, fields["MixedConstraints"])
     members = set(ref["CG_status"])
     assert members == {"solved", "bound_hit", "negative_curvature", "max_iter_reached"}
+    # the shim converts the library's integer with `BEnlsip.CG_status(code)`: the header's codes must be the enum's positions
+    header = open(os.path.join(ROOT, "include", "benlsip_hip.h")).read()
+    for pos, member in enumerate(ref["CG_status"]):
+        assert re.search(r"#define\s+BH_CG_%s\s+%d\b" % (member.upper(), pos), header), (member, pos)
+    assert "BEnlsip.CG_status(status[])" in src.replace(" ", "") or "BEnlsip.CG_status(status[])" in src
     for name in re.findall(r"BEnlsip\.(solved|bound_hit|negative_curvature|max_iter_reached|[a-z_]+_reached)\b", src):
         assert name in members, name
