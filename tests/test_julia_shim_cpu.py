@@ -288,3 +288,38 @@ def test_shim_touches_only_fields_and_enum_members_the_reference_has():
     assert "BEnlsip.CG_status(status[])" in src.replace(" ", "") or "BEnlsip.CG_status(status[])" in src
     for name in re.findall(r"BEnlsip\.(solved|bound_hit|negative_curvature|max_iter_reached|[a-z_]+_reached)\b", src):
         assert name in members, name
+
+
+def test_every_reference_function_the_shim_calls_exists_with_that_arity():
+    """Calls INTO the reference from the shim (`BEnlsip.cholesky_aug_aat(...)`, `invoke(BEnlsip.cauchy_step, Tuple{...}, ...)`, constructors):
+    the name is a function, struct or enum of the reference, and a plain call passes a number of positional arguments that one of its
+    methods takes."""
+    import importlib.util
+    import json
+    import re
+    gold = os.path.join(ROOT, "tests", "golden")
+    ref = json.load(open(os.path.join(gold, "reference_signatures.json")))
+    spec = importlib.util.spec_from_file_location("mrs", os.path.join(gold, "make_reference_signatures.py"))
+    mrs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mrs)
+    arities = {}
+    for f in mrs.FILES:
+        for s in ref[f]:
+            arities.setdefault(s["name"].split(".")[-1], set()).add(len(s["positional"]))
+    known = set(arities) | set(ref["struct_fields"]) | {"CG_status"}
+    src = _strip_julia(open(os.path.join(ROOT, "julia", "BEnlsipHIP.jl")).read())
+    n_calls = 0
+    for m in re.finditer(r"(function\s+)?BEnlsip\.([A-Za-z_]\w*!?)(\s*\()?", src):
+        is_def, name, call = m.group(1), m.group(2), m.group(3)
+        assert name in known, "BEnlsip.%s is not defined by the reference" % name
+        if is_def or not call or name not in arities:
+            continue                                    # a method definition, a bare reference (invoke, Tuple types) or a constructor
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        pos = src[m.end():i - 1].partition(";")[0]
+        n_args = len(mrs.split_args(pos))
+        assert n_args in arities[name], "BEnlsip.%s called with %d positional arguments; the reference has %s" % (name, n_args, sorted(arities[name]))
+        n_calls += 1
+    assert n_calls >= 1
