@@ -213,3 +213,24 @@ def test_stats_struct_matches_the_header(tmp_path):
     out = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     assert out[0] == C.sizeof(_lib.bh_stats_t)
     assert out[1:] == [getattr(_lib.bh_stats_t, f).offset for f in names]
+
+
+def test_python_mirror_keeps_the_reference_argument_order():
+    """benlsip.jl_amd/operators.py mirrors the reference's operators for the path: same names, same positional parameters in the same
+    order as tests/golden/reference_signatures.json records them — except the augmented factor `chol_aat`, which the device's
+    reduced projection form does not take (cauchy_step, inner_step), and linesearch's `fix_bounds`, read from `lincons`."""
+    import inspect
+    import json
+    import benlsip_jl_amd as bh
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "reference_signatures.json")))
+    by = {}
+    for f in ("basic_tralcnlss.jl", "polyhedral_constraints.jl"):
+        for s in ref[f]:
+            by.setdefault(s["name"].split(".")[-1].rstrip("!"), []).append(s["positional"])
+    for name in ("projected_cg", "minor_iterate", "cauchy_step", "inner_step", "vthv", "projection", "linesearch", "factor_to_boundary"):
+        fn = getattr(bh, name)
+        mine = [p.name for p in inspect.signature(fn).parameters.values()
+                if p.default is inspect.Parameter.empty and p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        wanted = [[a if a != "fix_bounds" else "lincons" for a in sig if a != "chol_aat"] for sig in by[name]]
+        assert mine in wanted, (name, mine, wanted)
