@@ -304,3 +304,29 @@ def test_oracle_minor_iterate_against_an_answer_derived_by_hand():
     cons = R.make_mixed_constraints(Z, R.chol_lower(Z @ Z.T), fix, l=-np.ones(4), u=np.ones(4))
     w, st = R.minor_iterate(x, np.zeros(4), g, R.AlHessian(np.eye(4), Z, 1.0), cons, 100.0, 0.1)
     assert int(st) == 0 and np.array_equal(w, np.where(fix, 0.0, -g))
+
+
+def test_oracle_functions_keep_the_reference_names_and_argument_order():
+    """The NumPy restatement follows the reference function by function; at the interface level that is checkable mechanically: for
+    the functions of the path and of the driver chain, the oracle has a function of the reference's name (`!` dropped) whose positional
+    parameters are the reference's, in order (tests/golden/reference_signatures.json) — with `chol_aat` carried as its lower factor
+    (`chol_aat_L`), `polyhedron` called `lincons`, and in-place output arguments returned instead."""
+    import inspect
+    import json
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_signatures.json")))
+    by = {}
+    for f in ("basic_tralcnlss.jl", "polyhedral_constraints.jl"):
+        for s in ref[f]:
+            by.setdefault(s["name"].split(".")[-1].rstrip("!"), []).append(s["positional"])
+    names = ["projected_cg", "minor_iterate", "cauchy_step", "inner_step", "vthv", "projection", "linesearch", "factor_to_boundary",
+             "next_breakpoint", "left_mul", "left_mul_tr", "update_tr", "initial_tr", "tralcnllss", "solve_subproblem", "active_bounds",
+             "add_active", "cholesky_aug_aat", "update_chol", "least_squares_multipliers", "norm_reduced_gradient", "projection_nullspace",
+             "projection_subspace"]
+    rename = {"chol_aat": "chol_aat_L", "polyhedron": "lincons", "indx": "ind"}
+    for name in names:
+        fn = getattr(R, name)
+        mine = [p.name for p in inspect.signature(fn).parameters.values()
+                if p.default is inspect.Parameter.empty and p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
+        wanted = [[rename.get(a, a) for a in sig] for sig in by[name]]
+        wanted += [w[:-1] for w in wanted if w and w[-1] == "v"]             # projection!(lincons, r, v) -> v = projection(lincons, r)
+        assert mine in wanted, (name, mine, wanted)
