@@ -1,5 +1,5 @@
 """Writes tests/golden/reference_signatures.json: for every `function name(...)` in the reference's live source files, its name and
-the number, names and type annotations of its POSITIONAL parameters (keywords after `;` listed separately); the field names of its structs and the members of `CG_status`.  Data about the reference's interface — what
+its first line, the number, names and type annotations of its POSITIONAL parameters (keywords after `;` listed separately); the field names of its structs, the members of `CG_status` and the length of each file.  Data about the reference's interface — what
 the Julia shim's more specific methods must line up with — not its source.  Run here (needs /root/reference); the fixture is committed.
     python tests/golden/make_reference_signatures.py"""
 import json
@@ -37,7 +37,8 @@ def signatures(text):
         pos, _, kw = inner.partition(";")
         names = lambda lst: [re.split(r"::|=", a)[0].strip() for a in lst]
         types = lambda lst: [re.sub(r"\s+", "", re.split(r"=", a.split("::", 1)[1])[0]) if "::" in a else "" for a in lst]
-        sigs.append({"name": m.group(1), "positional": names(split_args(pos)), "types": types(split_args(pos)), "keywords": names(split_args(kw))})
+        sigs.append({"name": m.group(1), "positional": names(split_args(pos)), "types": types(split_args(pos)), "keywords": names(split_args(kw)),
+                     "line": text.count("\n", 0, m.start()) + 1})
     return sigs
 
 
@@ -58,6 +59,7 @@ def build():
         out["struct_fields"].update(struct_fields(open(os.path.join(REF, f)).read()))
     enum = re.search(r"@enum\s+CG_status\s+([^\n]+)", open(os.path.join(REF, FILES[0])).read())
     out["CG_status"] = enum.group(1).split()
+    out["n_lines"] = {f: open(os.path.join(REF, f)).read().count("\n") for f in FILES}
     return out
 
 
@@ -65,7 +67,7 @@ def main():
     out = build()
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_signatures.json")
     json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
-    print({f: len(v) for f, v in out.items()})
+    print({f: (len(v) if hasattr(v, "__len__") else v) for f, v in out.items()})
     print(out["struct_fields"], out["CG_status"])
 
 

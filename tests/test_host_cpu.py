@@ -234,3 +234,33 @@ def test_python_mirror_keeps_the_reference_argument_order():
                 if p.default is inspect.Parameter.empty and p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)]
         wanted = [[a if a != "fix_bounds" else "lincons" for a in sig if a != "chol_aat"] for sig in by[name]]
         assert mine in wanted, (name, mine, wanted)
+
+
+def test_citations_point_into_the_reference():
+    """`include/benlsip_hip.h` cites, for every entry point, the reference lines it replaces.  Against the interface fixture
+    (tests/golden/reference_signatures.json: first line of every reference function, length of each file): a citation of the form
+    `name(args) — src/file.jl:A-B` names a function of the reference whose definition starts inside [A, B], and no citation anywhere
+    in the header, the design documents or the oracle points past the end of its file."""
+    import glob
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "reference_signatures.json")))
+    starts = {}
+    for f in ("basic_tralcnlss.jl", "polyhedral_constraints.jl"):
+        for s in ref[f]:
+            starts.setdefault((f, s["name"].split(".")[-1].lstrip(":")), []).append(s["line"])
+    header = open(os.path.join(root, "include", "benlsip_hip.h")).read()
+    n_checked = 0
+    for m in re.finditer(r"([A-Za-z_][\w.:*]*!?)\s*\([^)\n]*\)[^\n—]*— src/(\w+\.jl):(\d+)(?:-(\d+))?", header):
+        name, f, a = m.group(1).split(".")[-1].lstrip(":"), m.group(2), int(m.group(3))
+        b = int(m.group(4) or a)
+        if (f, name) in starts:
+            assert any(a <= s <= b for s in starts[(f, name)]), (name, f, a, b, starts[(f, name)])
+            n_checked += 1
+    assert n_checked >= 10
+    files = [os.path.join(root, "include", "benlsip_hip.h"), os.path.join(root, "DESIGN.md"), os.path.join(root, "INTEGRATION.md"),
+             os.path.join(root, "julia", "BEnlsipHIP.jl")] + glob.glob(os.path.join(root, "oracle", "*.py")) + glob.glob(os.path.join(root, "oracle", "*.c"))
+    for path in files:
+        for f, a, b in re.findall(r"(basic_tralcnlss\.jl|polyhedral_constraints\.jl):(\d+)(?:-(\d+))?", open(path).read()):
+            assert int(b or a) <= ref["n_lines"][f] and int(a) >= 1 and int(a) <= int(b or a), (os.path.relpath(path, root), f, a, b)
