@@ -32,3 +32,21 @@ def test_every_tool_and_test_named_in_the_documents_exists():
             if ("def %s(" % name) not in test_src:
                 missing.append((doc, name))
     assert not missing, missing
+
+
+def test_every_kernel_and_entry_point_named_in_the_documents_exists():
+    """`…_kernel` names in the design documents are kernels of `benlsip.jl_amd/csrc`, `bh_…` names are exports of the header (or
+    options / struct members documented there)."""
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "benlsip.jl_amd", "csrc", "*")))
+    header = open(os.path.join(ROOT, "include", "benlsip_hip.h")).read()
+    missing = []
+    for doc, text in _text().items():
+        if doc.startswith("docs/design_history"):
+            continue                                    # the engineering log also names kernels that were tried and removed
+        for name in set(re.findall(r"`([a-z][a-z0-9_]*_kernel)\b", text)):
+            if not re.search(r"\b%s\b" % re.escape(name), src):
+                missing.append((doc, name))
+        for name in set(re.findall(r"`(bh_[a-z0-9_]+)`", text)):
+            if not re.search(r"\b%s\b" % re.escape(name), header):
+                missing.append((doc, name))
+    assert not missing, missing
